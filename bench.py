@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + shadow + reflect) on scenes/bunny.scene at
+1920x1080x16spp (BASELINE.json), one process per GPU, frame image-tiled over the ranks.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = one full frame: every rank renders its interleaved 8-row bands of the frame through the
+C ABI with the frame left in HBM (out_rgb = NULL); scene, jitter pattern and pixel lists are
+HBM-resident before the timed region.  The K steps are bracketed by barrier + device synchronise
+and the slowest rank's wall time counts: `value` = rays traced by all ranks / that time.  After the
+timed region every rank fetches its bands once (ft_fetch_frame) and rank 0 gathers them on the host;
+the PCIe-inclusive frame time is reported as `frame_ms_incl_copy`, never as `value`.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+RAY_REC, HIT_REC = 60, 16         # bytes, functracer_amd/csrc/ft_device.h
+ALGO_BYTES_PER_RAY = 2 * RAY_REC + 2 * HIT_REC   # each record written once and read once
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="bunny")
+    ap.add_argument("--res", type=int, nargs=2, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import functracer_amd as ft
+    from functracer_amd import tiling
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")          # RCCL: used for the barrier / timing reduction only, never for pixels
+        host_group = dist.new_group(backend="gloo")
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    scene = ft.parse_scene_file(os.path.join(ROOT, "scenes", args.scene + ".scene"))
+    res_h, res_v = args.res if args.res else scene.resolution
+    spp = args.spp if args.spp else scene.samples
+    jitter = ft.jitter_pattern(spp)
+    ctx = ft.Context(device=local_rank)
+    scene.lower(ctx)
+    bands = None if world == 1 else tiling.bands_for_rank(res_h, res_v, rank, world)
+    frame = np.zeros((res_v, res_h, 3))
+
+    def step():
+        _, st = ctx.render(scene.camera, res_h, res_v, spp, jitter, tiles=bands, fetch=False)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync()
+    t0 = time.perf_counter()
+    rays = 0
+    kernel_ms = trace_ms = 0.0
+    k_times = {"generate": 0.0, "closest": 0.0, "shade": 0.0, "blend": 0.0}
+    k_launch = dict.fromkeys(k_times, 0)
+    st = None
+    for _ in range(args.steps):
+        st = step()
+        rays += st["rays_traced"]
+        kernel_ms += st["kernel_ms"]
+        trace_ms += st["trace_kernel_ms"]
+        for k, v in ctx.kernel_times().items():
+            k_times[k] += v["ms"]
+            k_launch[k] += v["launches"]
+    barrier_sync()
+    wall = time.perf_counter() - t0
+
+    # slowest rank's times; total rays over ranks
+    vals = torch.tensor([wall, kernel_ms], dtype=torch.float64)
+    tot = torch.tensor([float(rays)], dtype=torch.float64)
+    if world > 1:
+        vals = vals.cuda(); tot = tot.cuda()
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        vals = vals.cpu(); tot = tot.cpu()
+    wall_max, kernel_ms_max = float(vals[0]), float(vals[1])
+    rays_total = float(tot[0])
+
+    # D2H of this rank's bands + gather on the host of rank 0 (outside the timed region; reported separately)
+    tg = time.perf_counter()
+    ctx.fetch_frame(frame)
+    copy_ms = (time.perf_counter() - tg) * 1e3
+    full = tiling.gather_frame(frame, res_h, res_v, rank, world, group=host_group if world > 1 else None)
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    if rank == 0 and os.environ.get("FT_BENCH_PNG"):
+        ft.write_png(os.environ["FT_BENCH_PNG"], ft.quantise_rgba8(full))
+
+    if rank == 0:
+        steps = args.steps
+        mrays_wall = rays_total / wall_max / 1e6                        # inputs and frame resident in HBM; barrier-to-barrier wall time
+        mrays_kernel = rays_total / (kernel_ms_max * 1e-3) / 1e6       # same rays over the HIP-event kernel time of the slowest rank
+        dom = max(("closest", "shade"), key=lambda k: k_times[k])
+        dom_avg_ms = k_times[dom] / max(1, k_launch[dom])
+        # rays a launch of the dominant kernel processes: closest sees every ray; shade sees the hits (its shadow rays are its work)
+        rays_rank = rays / steps
+        if dom == "closest":
+            rays_per_launch = (st["rays_primary"] + st["rays_reflect"]) / max(1, k_launch[dom] / steps)
+        else:
+            rays_per_launch = st["rays_shadow"] / max(1, k_launch[dom] / steps)
+        achieved = ALGO_BYTES_PER_RAY * rays_per_launch / (dom_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (primary+shadow+reflect) at 1920x1080x16spp; frame ms",
+            "value": round(mrays_wall, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall_max / steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"scenes/{args.scene}.scene {res_h}x{res_v}x{spp}spp, depth 8, synthetic bunny stand-in mesh (980 tris), seeded jitter",
+                       "parallelism": f"image-tiled, {world} rank(s) x interleaved {tiling.BAND_ROWS}-row bands, no collective on the data path"},
+            "kernel_ms_per_step": round(kernel_ms_max / steps, 4),
+            "value_kernel_only": round(mrays_kernel, 3),
+            "frame_ms_incl_copy": round(wall_max / steps * 1e3 + gather_ms, 4),
+            "d2h_copy_ms": round(copy_ms, 3),
+            "gather_ms": round(gather_ms, 3),
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_ray": ALGO_BYTES_PER_RAY},
+            "per_kernel_ms_per_step": {k: round(v / steps, 4) for k, v in k_times.items()},
+        }
+        out["rays_per_frame"] = {"traced_rank0": int(rays_rank), "traced_all_ranks": int(rays_total / steps),
+                                 "reference_equivalent_rank0": st["rays_reference_equivalent"]}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, res_h, res_v, spp, jitter, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(scene, res_h, res_v, spp, jitter, budget_s):
+    """The CPU oracle (a C++ port of the F# algorithm; the F# toolchain does not exist here) timed on
+    this box's host cores on a bounded sample: interleaved 8-row bands of the same frame."""
+    import numpy as np
+
+    from functracer_amd import tiling
+    from oracle import ft_oracle_py as O
+    orc = O.Oracle()
+    scene.lower(orc)
+    cores = os.cpu_count() or 1
+    # calibrate on a thin sample, then size the real sample to ~budget_s
+    probe = tiling.bands_for_rank(res_h, res_v, 0, 64)
+    frame = np.zeros((res_v, res_h, 3))
+    _, st = orc.render(scene.camera, res_h, res_v, spp, jitter, tiles=probe, threads=cores, out=frame)
+    rate = st["rays_traced"] / (st["wall_ms"] * 1e-3)
+    frac = min(1.0, max(1.0 / 64, budget_s * rate / (st["rays_traced"] * 64)))
+    stride = max(1, int(round(1.0 / frac)))
+    sample = tiling.bands_for_rank(res_h, res_v, 0, stride)
+    _, st = orc.render(scene.camera, res_h, res_v, spp, jitter, tiles=sample, threads=cores, out=frame)
+    return {"value": round(st["rays_traced"] / (st["wall_ms"] * 1e-3) / 1e6, 4), "unit": "Mrays/s", "cores": int(st["threads"]), "kind": "port",
+            "sample": f"every {stride}th 8-row band of the same {res_h}x{res_v}x{spp}spp frame ({st['rays_traced']} rays, {st['wall_ms'] / 1e3:.1f} s), "
+                      "C++ restatement of the F# algorithm (oracle/ft_oracle.cpp); the F# toolchain is unavailable"}
+
+
+if __name__ == "__main__":
+    main()

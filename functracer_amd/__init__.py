@@ -1,0 +1,252 @@
+"""functracer_amd — Python face of the MI355X-native FuncTracer render loop.
+
+The product is `lib/libfunctracer_hip.so` (hand-written gfx950 kernels behind the C ABI of
+include/functracer_hip.h) plus `lib/libfunctracer_host.so` (the host side that is F# in the
+reference: SceneParser / PlyParser / Program).  This package only binds them; nothing here
+computes pixels, and nothing here touches the CPU oracle under oracle/.  If the HIP library or a
+GPU is missing, `Context()` raises — there is no fallback path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import (CIRCLE, CONE, CUBE, CYLINDER, EXCLUDE, INTERSECT, PLANE, SOLID_CYLINDER, SPHERE, SQUARE, SUBTRACT, UNION,
+                    FtError, SceneBuilder, make_camera)
+
+__all__ = ["Context", "ParsedScene", "parse_scene", "parse_scene_file", "jitter_pattern", "quantise_rgba8", "write_png",
+           "parse_colour", "parse_ply", "FtError", "make_camera", "HIP_LIB", "HOST_LIB", "DEFAULT_SEED"]
+
+HIP_LIB = os.path.join(_capi.LIB_DIR, "libfunctracer_hip.so")
+HOST_LIB = os.path.join(_capi.LIB_DIR, "libfunctracer_host.so")
+DEFAULT_SEED = 20260104          # jitter pattern seed of the BASELINE configs
+MAX_DEPTH = 8                    # Shading.fs:142
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        lib = _capi.load_library(HIP_LIB)
+        lib.ft_create.argtypes = [_capi.c_int32_p, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.ft_create_host_only.argtypes = [C.POINTER(C.c_void_p)]
+        lib.ft_destroy.argtypes = [C.c_void_p]
+        lib.ft_destroy.restype = None
+        lib.ft_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.ft_render.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32,
+                                  C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32, _capi.c_double_p, C.POINTER(_capi.ft_stats)]
+        lib.ft_fetch_frame.argtypes = [C.c_void_p, _capi.c_double_p]
+        lib.ft_debug_closest.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, _capi.c_int32_p,
+                                         _capi.c_double_p, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p]
+        lib.ft_debug_blocked.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, _capi.c_int32_p]
+        lib.ft_debug_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        lib.ft_debug_slice.argtypes = [_capi.c_double_p] * 4 + [_capi.c_int32_p, _capi.c_double_p, _capi.c_int32_p]
+        lib.ft_get_kernel_times.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_int32_p]
+        lib.ft_quantise_rgba8.argtypes = [_capi.c_double_p, C.c_int64, C.POINTER(C.c_uint8)]
+        _hip = lib
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        lib = _capi.load_library(HOST_LIB)
+        lib.fth_parse_scene.restype = C.c_void_p
+        lib.fth_parse_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
+        lib.fth_parse_scene_file.restype = C.c_void_p
+        lib.fth_parse_scene_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+        lib.fth_scene_free.argtypes = [C.c_void_p]
+        lib.fth_scene_free.restype = None
+        lib.fth_scene_options.argtypes = [C.c_void_p, C.POINTER(_capi.fth_options)]
+        lib.fth_scene_counts.argtypes = [C.c_void_p, _capi.c_int32_p, _capi.c_int32_p]
+        lib.fth_scene_lower.argtypes = [C.c_void_p, C.POINTER(_capi.fth_builder), C.c_void_p]
+        lib.fth_parse_colour.argtypes = [C.c_char_p, _capi.c_double_p]
+        lib.fth_parse_ply.restype = C.c_int64
+        lib.fth_parse_ply.argtypes = [C.c_char_p, _capi.c_double_p, C.c_int64, C.c_char_p, C.c_int32]
+        lib.fth_jitter_pattern.argtypes = [C.c_uint64, C.c_int32, _capi.c_double_p]
+        lib.fth_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]
+        _host = lib
+    return _host
+
+
+class ParsedScene:
+    """Result of SceneParser.parse (SceneParser.fs:360-366): (SceneOptions, Scene)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        opt = _capi.fth_options()
+        host_lib().fth_scene_options(handle, C.byref(opt))
+        self.camera = opt.camera
+        self.resolution = (opt.res_h, opt.res_v)
+        self.samples = opt.samples
+        self.corner = bool(opt.corner)
+        n_obj, n_l = C.c_int32(), C.c_int32()
+        host_lib().fth_scene_counts(handle, C.byref(n_obj), C.byref(n_l))
+        self.n_objects, self.n_lights = n_obj.value, n_l.value
+
+    def lower(self, builder):
+        """Hand the scene to anything with a SceneBuilder (`Context`, or the oracle in tests)."""
+        rc = host_lib().fth_scene_lower(self._h, C.byref(builder.table), builder._ctx)
+        if rc < 0:
+            raise FtError(rc, builder.last_error())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _host is not None:
+            _host.fth_scene_free(self._h)
+            self._h = None
+
+
+def parse_scene(text, base_dir=""):
+    err = C.create_string_buffer(2048)
+    h = host_lib().fth_parse_scene(text.encode(), base_dir.encode(), err, len(err))
+    if not h:
+        raise ValueError(err.value.decode())
+    return ParsedScene(h)
+
+
+def parse_scene_file(path):
+    err = C.create_string_buffer(2048)
+    h = host_lib().fth_parse_scene_file(os.fspath(path).encode(), err, len(err))
+    if not h:
+        raise ValueError(err.value.decode())
+    return ParsedScene(h)
+
+
+def parse_colour(text):
+    rgb = np.zeros(3)
+    if host_lib().fth_parse_colour(text.encode(), _capi.dptr(rgb)) != 0:
+        raise ValueError("Parsing failed")
+    return tuple(rgb)
+
+
+def parse_ply(text):
+    err = C.create_string_buffer(1024)
+    n = host_lib().fth_parse_ply(text.encode(), None, 0, err, len(err))
+    if n < 0:
+        raise ValueError(err.value.decode())
+    out = np.zeros((n, 9))
+    host_lib().fth_parse_ply(text.encode(), _capi.dptr(out), n, err, len(err))
+    return out
+
+
+def jitter_pattern(n, seed=DEFAULT_SEED):
+    """Jitter.pattern random Jitter.circle n on the documented seeded stream (host_api.h)."""
+    out = np.zeros((n, 2))
+    host_lib().fth_jitter_pattern(int(seed), int(n), _capi.dptr(out))
+    return out
+
+
+def quantise_rgba8(rgb):
+    """Image.write's toByte (Image.fs:36)."""
+    rgb = _capi.as_f64(rgb)
+    n = rgb.size // 3
+    out = np.zeros((n, 4), dtype=np.uint8)
+    rc = hip_lib().ft_quantise_rgba8(_capi.dptr(rgb), n, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc < 0:
+        raise FtError(rc)
+    return out.reshape(rgb.shape[:-1] + (4,))
+
+
+def write_png(path, rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w = rgba.shape[:2]
+    rc = host_lib().fth_write_png(os.fspath(path).encode(), rgba.ctypes.data_as(C.POINTER(C.c_uint8)), w, h)
+    if rc < 0:
+        raise FtError(rc, "write_png")
+
+
+class Context(SceneBuilder):
+    """One ft_context on one MI355X.  `host_only=True` gives the test hook that can build and flatten
+    scenes but never renders."""
+
+    def __init__(self, device=0, host_only=False):
+        lib = hip_lib()
+        h = C.c_void_p()
+        if host_only:
+            rc = lib.ft_create_host_only(C.byref(h))
+        else:
+            dev = (C.c_int32 * 1)(int(device))
+            rc = lib.ft_create(dev, 1, C.byref(h))
+        if rc < 0:
+            raise FtError(rc, "ft_create: no usable HIP device (the HIP path has no CPU fallback)" if rc == -2 else "ft_create")
+        self.device = device
+        super().__init__(lib, "ft_", h)
+
+    def close(self):
+        if self._ctx:
+            self._lib.ft_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self._check(self._lib.ft_set_option(self._ctx, key.encode(), int(value)))
+
+    def render(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None, out=None, fetch=True):
+        """Program.fs:54-64 on the GPU.  Returns (rgb[res_v, res_h, 3] float64, stats dict).  With
+        fetch=False the frame stays in HBM (returns (None, stats)); `fetch_frame` copies it out later."""
+        jitter = _capi.as_f64(jitter, (spp, 2))
+        if fetch and out is None:
+            out = np.zeros((res_v, res_h, 3))
+        rects, n_rects = _capi.make_rects(tiles)
+        st = _capi.ft_stats()
+        rc = self._lib.ft_render(self._ctx, C.byref(camera), res_h, res_v, spp, _capi.dptr(jitter), max_depth, int(seed), rects, n_rects,
+                                 _capi.dptr(out) if fetch else None, C.byref(st))
+        self._check(rc)
+        return (out if fetch else None), st.as_dict()
+
+    def fetch_frame(self, out):
+        self._check(self._lib.ft_fetch_frame(self._ctx, _capi.dptr(out)))
+        return out
+
+    def kernel_times(self):
+        ms = np.zeros(4)
+        n = np.zeros(4, dtype=np.int32)
+        self._check(self._lib.ft_get_kernel_times(self._ctx, _capi.dptr(ms), n.ctypes.data_as(_capi.c_int32_p)))
+        names = ["generate", "closest", "shade", "blend"]
+        return {k: {"ms": float(ms[i]), "launches": int(n[i])} for i, k in enumerate(names)}
+
+    def closest(self, origins, dirs):
+        """Scene.intersectScene (Scene.fs:118) for explicit rays, through the device path."""
+        o = _capi.as_f64(origins).reshape(-1, 3)
+        d = _capi.as_f64(dirs).reshape(-1, 3)
+        n = o.shape[0]
+        hit = np.zeros(n, dtype=np.int32)
+        t, p, nr, col = np.zeros(n), np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+        self._check(self._lib.ft_debug_closest(self._ctx, _capi.dptr(o), _capi.dptr(d), n, hit.ctypes.data_as(_capi.c_int32_p),
+                                               _capi.dptr(t), _capi.dptr(p), _capi.dptr(nr), _capi.dptr(col)))
+        return hit, t, p, nr, col
+
+    def blocked(self, origins, dirs, max_dist):
+        """Scene.lightIsBocked (Scene.fs:119-121) for explicit rays, through the device path."""
+        o = _capi.as_f64(origins).reshape(-1, 3)
+        d = _capi.as_f64(dirs).reshape(-1, 3)
+        m = _capi.as_f64(max_dist).reshape(-1)
+        out = np.zeros(o.shape[0], dtype=np.int32)
+        self._check(self._lib.ft_debug_blocked(self._ctx, _capi.dptr(o), _capi.dptr(d), _capi.dptr(m), o.shape[0], out.ctypes.data_as(_capi.c_int32_p)))
+        return out
+
+    def scene_info(self):
+        out = (C.c_int64 * 8)()
+        self._check(self._lib.ft_debug_scene_info(self._ctx, out))
+        keys = ["leaves", "program_words", "meshes", "bsp_nodes", "bsp_leaves", "triangles", "csg_capacity", "stack_capacity"]
+        return dict(zip(keys, list(out)))
+
+
+def debug_slice(p0, n, tri):
+    """Triangle.slice as implemented by the product's BSP builder."""
+    above, below = np.zeros(18), np.zeros(18)
+    na, nb = C.c_int32(), C.c_int32()
+    tri = _capi.as_f64(tri, (9,))
+    rc = hip_lib().ft_debug_slice(_capi.dptr(_capi.as_f64(p0)), _capi.dptr(_capi.as_f64(n)), _capi.dptr(tri), _capi.dptr(above), C.byref(na),
+                                  _capi.dptr(below), C.byref(nb))
+    if rc < 0:
+        raise FtError(rc, "slice")
+    return above[:9 * na.value].reshape(-1, 3, 3), below[:9 * nb.value].reshape(-1, 3, 3)

@@ -1,0 +1,536 @@
+// ft_capi.cpp — the C ABI of libfunctracer_hip.so (include/functracer_hip.h): context, scene
+// builder, HBM residency of the flattened scene and the per-frame wavefront pipeline driver.
+// Reference citations are relative to /root/reference/FuncTracer/.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/functracer_hip.h"
+#include "ft_device.h"
+#include "ft_scene.h"
+
+namespace ftk {
+int occupancy_blocks_closest(size_t lds_bytes);
+int occupancy_blocks_shade(size_t lds_bytes);
+}
+
+struct DeviceBuf {
+    void* p = nullptr; size_t bytes = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ft_context {
+    bool host_only = false;
+    int device = -1;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    fth::SceneGraph graph;
+    fth::FlatScene flat;
+    bool committed = false;
+
+    int64_t chunk_samples = 8ll << 20;
+
+    // scene in HBM
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris;
+    ftk::DevScene dev_scene{};
+    // frame buffers in HBM
+    DeviceBuf d_rays[2], d_hits, d_hit_list, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
+    int64_t ray_capacity = 0;
+    std::vector<hipEvent_t> events;
+    size_t events_used = 0;
+    std::vector<uint32_t> last_pixels;   // tile pixel ids of the last render (empty = whole frame)
+    int64_t last_n_pix = 0;
+    int32_t last_res_h = 0, last_res_v = 0;
+    double k_ms[4] = {0, 0, 0, 0};
+    int32_t k_launches[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+#define FT_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return FT_ERR_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+int32_t ensure(ft_context* c, DeviceBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return FT_OK;
+    if (b.p) { FT_HIP(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    FT_HIP(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return FT_OK;
+}
+template <class T> int32_t upload(ft_context* c, DeviceBuf& b, const std::vector<T>& v) {
+    int32_t rc = ensure(c, b, v.size() * sizeof(T));
+    if (rc != FT_OK) return rc;
+    if (!v.empty()) FT_HIP(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return FT_OK;
+}
+void release(DeviceBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+
+bool need_device(ft_context* c) {
+    if (!c) return false;
+    if (c->host_only) { c->err = "host-only context: no HIP device bound (there is no CPU fallback for rendering)"; return false; }
+    return true;
+}
+
+ftk::RayBuf ray_view(const DeviceBuf& b, int64_t cap) {
+    double* d = b.as<double>();
+    ftk::RayBuf r;
+    r.ox = d; r.oy = d + cap; r.oz = d + 2 * cap; r.dx = d + 3 * cap; r.dy = d + 4 * cap; r.dz = d + 5 * cap; r.w = d + 6 * cap;
+    r.slot = reinterpret_cast<uint32_t*>(d + 7 * cap);
+    return r;
+}
+
+int32_t ensure_frame_buffers(ft_context* c, int64_t cap) {
+    if (cap <= c->ray_capacity) return FT_OK;
+    int32_t rc;
+    for (int i = 0; i < 2; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_hits, (size_t)cap * 16)) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_hit_list, (size_t)cap * 4)) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_acc, (size_t)cap * 24)) != FT_OK) return rc;
+    c->ray_capacity = cap;
+    return FT_OK;
+}
+
+hipEvent_t next_event(ft_context* c) {
+    if (c->events_used == c->events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->events.push_back(e); }
+    return c->events[c->events_used++];
+}
+
+// ImagePlane.create (Image.fs:48-53, 67-81), evaluated once per frame on the host.
+ftk::Camera make_camera(const ft_camera& cam, int res_h, int res_v) {
+    auto norm = [](double v[3]) { double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); if (!(l < 0.0000001)) { double s = 1.0 / l; v[0] = s * v[0]; v[1] = s * v[1]; v[2] = s * v[2]; } };
+    ftk::Camera out{};
+    double k[3] = {cam.look_at[0] - cam.o[0], cam.look_at[1] - cam.o[1], cam.look_at[2] - cam.o[2]};
+    norm(k);
+    const double* u = cam.up;
+    double i[3] = {u[1] * k[2] - u[2] * k[1], k[0] * u[2] - k[2] * u[0], u[0] * k[1] - u[1] * k[0]};     // up .** k
+    norm(i);
+    double j[3] = {k[1] * i[2] - k[2] * i[1], i[0] * k[2] - i[2] * k[0], k[0] * i[1] - k[1] * i[0]};     // k .** i
+    const double height = std::tan(cam.fov_y / 2.0) * 2.0;
+    const double width = height * cam.aspect_ratio;
+    const double pixel_height = height / (double)(res_h - 1);      // sic, Image.fs:71: resH
+    const double pixel_width = width / (double)(res_v - 1);        // sic, Image.fs:72: resV
+    for (int a = 0; a < 3; ++a) { out.o[a] = cam.o[a]; out.k[a] = k[a]; out.i[a] = i[a]; out.j[a] = j[a]; }
+    out.pw = pixel_width; out.ph = pixel_height;
+    out.tlx = -width / 2.0 + pixel_width / 2.0; out.tly = height / 2.0 - pixel_height / 2.0;
+    out.res_h = res_h; out.res_v = res_v;
+    return out;
+}
+
+size_t lds_bytes_for(const fth::FlatScene& f) { return (size_t)(4 * f.csg_capacity + f.stack_capacity) * ftk::kBlock * 4; }
+
+} // namespace
+
+extern "C" {
+
+int32_t ft_abi_version(void) { return FT_ABI_VERSION; }
+
+int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out) {
+    if (!out) return FT_ERR_INVALID;
+    *out = nullptr;
+    if (n_devices < 1 || !device_ids) return FT_ERR_NO_DEVICE;     // no CPU backend exists in this library
+    if (n_devices > 1) return FT_ERR_UNSUPPORTED;                  // one context per device; frames are tiled across contexts/processes
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return FT_ERR_NO_DEVICE;
+    if (device_ids[0] < 0 || device_ids[0] >= count) return FT_ERR_INVALID;
+    ft_context* c = new ft_context();
+    c->device = device_ids[0];
+    hipDeviceProp_t prop;
+    if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FT_ERR_HIP; }
+    c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return FT_OK;
+}
+
+int32_t ft_create_host_only(ft_context** out) {
+    if (!out) return FT_ERR_INVALID;
+    ft_context* c = new ft_context();
+    c->host_only = true;
+    *out = c;
+    return FT_OK;
+}
+
+void ft_destroy(ft_context* c) {
+    if (!c) return;
+    if (!c->host_only) {
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris,
+                             &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
+                             &c->d_dbg_in, &c->d_dbg_out};
+        for (auto* b : bufs) release(*b);
+        for (auto e : c->events) (void)hipEventDestroy(e);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+const char* ft_last_error(const ft_context* c) { return c ? c->err.c_str() : "null context"; }
+
+int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
+    if (!c || !key) return FT_ERR_INVALID;
+    if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; return FT_OK; }
+    if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
+    c->err = std::string("unknown option: ") + key;
+    return FT_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------ builder
+static ft_node add_node(ft_context* c, fth::GraphNode&& n) { c->graph.nodes.push_back(std::move(n)); c->committed = false; return (ft_node)c->graph.nodes.size() - 1; }
+
+ft_node ft_sg_primitive(ft_context* c, int32_t kind) {
+    if (!c || kind < 0 || kind > FT_PRIM_CYLINDER) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::Prim; n.prim = kind; return add_node(c, std::move(n));
+}
+ft_node ft_sg_triangle(ft_context* c, const double v[9]) {
+    if (!c || !v) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::TriangleP; std::memcpy(n.tri, v, sizeof n.tri); return add_node(c, std::move(n));
+}
+ft_node ft_sg_bsp_mesh(ft_context* c, int32_t depth, const double* tris, int64_t n_tris) {
+    if (!c || n_tris < 0 || (n_tris > 0 && !tris) || depth < 0) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::Mesh; n.depth = depth; n.tris.assign(tris, tris + 9 * n_tris); return add_node(c, std::move(n));
+}
+ft_node ft_sg_transform(ft_context* c, const ft_transform* ts, int32_t n_ts, ft_node child) {
+    if (!c || !c->graph.valid(child) || !ts || n_ts < 1) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::Transform;
+    for (int i = 0; i < n_ts; ++i) { if (ts[i].kind < FT_TRANSLATE || ts[i].kind > FT_ROTATE) return FT_ERR_INVALID; n.xf.push_back(ts[i]); }
+    n.children = {child};
+    return add_node(c, std::move(n));
+}
+ft_node ft_sg_material(ft_context* c, const ft_material* m, ft_node child) {
+    if (!c || !c->graph.valid(child) || !m) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::MaterialF; n.mat = *m; n.children = {child}; return add_node(c, std::move(n));
+}
+ft_node ft_sg_hue_shift(ft_context* c, double, ft_node child) {
+    if (!c || !c->graph.valid(child)) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::HueShift; n.children = {child}; return add_node(c, std::move(n));
+}
+ft_node ft_sg_ignore_light(ft_context* c, ft_node child) {
+    if (!c || !c->graph.valid(child)) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::IgnoreLight; n.children = {child}; return add_node(c, std::move(n));
+}
+ft_node ft_sg_group(ft_context* c, const ft_node* children, int32_t n_children) {
+    if (!c || n_children < 0 || (n_children > 0 && !children)) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::Group;
+    for (int i = 0; i < n_children; ++i) { if (!c->graph.valid(children[i])) return FT_ERR_INVALID; n.children.push_back(children[i]); }
+    return add_node(c, std::move(n));
+}
+ft_node ft_sg_csg(ft_context* c, int32_t op, ft_node a, ft_node b) {
+    if (!c || !c->graph.valid(a) || !c->graph.valid(b) || op < FT_CSG_UNION || op > FT_CSG_EXCLUDE) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::Csg; n.op = op; n.children = {a, b}; return add_node(c, std::move(n));
+}
+ft_node ft_sg_texture_grid(ft_context* c, const double ca[3], const double cb[3], const double* uv_ops, int32_t n_uv_ops, ft_node child) {
+    if (!c || !c->graph.valid(child) || !ca || !cb || n_uv_ops < 0 || (n_uv_ops > 0 && !uv_ops)) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::Texture;
+    std::memcpy(n.ca, ca, sizeof n.ca); std::memcpy(n.cb, cb, sizeof n.cb);
+    n.uv_ops.assign(uv_ops, uv_ops + 3 * n_uv_ops); n.children = {child};
+    return add_node(c, std::move(n));                               // rejected at commit until textures reach the device path
+}
+
+int32_t ft_scene_clear(ft_context* c) {
+    if (!c) return FT_ERR_INVALID;
+    c->graph.nodes.clear(); c->graph.lights.clear(); c->graph.root = -1; c->committed = false;
+    return FT_OK;
+}
+int32_t ft_scene_set_objects(ft_context* c, ft_node root) {
+    if (!c || !c->graph.valid(root)) return FT_ERR_INVALID;
+    c->graph.root = root; c->committed = false;
+    return FT_OK;
+}
+static void norm3(double v[3]) {                                    // Vector.normalise (CommonTypes.fs:63-67)
+    double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (!(l < 0.0000001)) { double s = 1.0 / l; v[0] = s * v[0]; v[1] = s * v[1]; v[2] = s * v[2]; }
+}
+int32_t ft_scene_add_directional(ft_context* c, const double dir[3], const double colour[3]) {      // Light.directional (Light.fs:19-20)
+    if (!c || !dir || !colour) return FT_ERR_INVALID;
+    ftd::Light l{}; l.kind = ftd::LT_DIRECTIONAL;
+    std::memcpy(l.v, dir, sizeof l.v); norm3(l.v); std::memcpy(l.colour, colour, sizeof l.colour);
+    c->graph.lights.push_back(l); c->committed = false;
+    return FT_OK;
+}
+int32_t ft_scene_add_soft_directional(ft_context* c, const double dir[3], int32_t samples, double scatter_rad, const double colour[3]) {  // Light.fs:22-23
+    if (!c || !dir || !colour || samples < 1) return FT_ERR_INVALID;
+    ftd::Light l{}; l.kind = ftd::LT_SOFT; l.samples = samples; l.scatter = scatter_rad;
+    std::memcpy(l.v, dir, sizeof l.v); norm3(l.v); std::memcpy(l.colour, colour, sizeof l.colour);
+    c->graph.lights.push_back(l); c->committed = false;            // rejected at commit until the seeded stream lands
+    return FT_OK;
+}
+int32_t ft_scene_add_positional(ft_context* c, const double pos[3], const double falloff[3], const double colour[3]) {  // Light.fs:25-26
+    if (!c || !pos || !falloff || !colour) return FT_ERR_INVALID;
+    ftd::Light l{}; l.kind = ftd::LT_POINT;
+    std::memcpy(l.v, pos, sizeof l.v); std::memcpy(l.falloff, falloff, sizeof l.falloff); std::memcpy(l.colour, colour, sizeof l.colour);
+    c->graph.lights.push_back(l); c->committed = false;
+    return FT_OK;
+}
+
+int32_t ft_scene_commit(ft_context* c) {
+    if (!c) return FT_ERR_INVALID;
+    int32_t rc = c->graph.flatten(c->flat, c->err);
+    if (rc != FT_OK) return rc;
+    if (c->host_only) { c->committed = true; return FT_OK; }
+    FT_HIP(c, hipSetDevice(c->device));
+    const fth::FlatScene& f = c->flat;
+    if (lds_bytes_for(f) > 160 * 1024) { c->err = "scene needs more than 160 KiB of LDS per workgroup for CSG lists / BSP stacks"; return FT_ERR_UNSUPPORTED; }
+    if ((rc = upload(c, c->d_leaves, f.leaves)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_m2w, f.m2w)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_materials, f.materials)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_lights, f.lights)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_program, f.program)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_meshes, f.meshes)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_nodes, f.nodes)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_bleaves, f.bsp_leaves)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_tris, f.tris)) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters))) != FT_OK) return rc;
+    FT_HIP(c, hipStreamSynchronize(c->stream));
+    ftk::DevScene& S = c->dev_scene;
+    S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
+    S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>();
+    S.program = c->d_program.as<uint32_t>(); S.meshes = c->d_meshes.as<ftd::Mesh>();
+    S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>();
+    S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
+    S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
+    c->committed = true;
+    return FT_OK;
+}
+
+// Copy the pixels of the last ft_render from HBM into the caller's frame (row 0 = top, Image.fs:39).
+int32_t ft_fetch_frame(ft_context* c, double* out_rgb) {
+    if (!c || !out_rgb) return FT_ERR_INVALID;
+    if (!need_device(c)) return FT_ERR_NO_DEVICE;
+    if (c->last_n_pix <= 0) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
+    FT_HIP(c, hipSetDevice(c->device));
+    const int64_t n = c->last_n_pix;
+    if (c->last_pixels.empty()) {
+        FT_HIP(c, hipMemcpy(out_rgb, c->d_out.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<double> packed((size_t)n * 3);
+        FT_HIP(c, hipMemcpy(packed.data(), c->d_out.p, packed.size() * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) std::memcpy(out_rgb + 3 * (size_t)c->last_pixels[(size_t)i], &packed[3 * (size_t)i], 24);
+    }
+    return FT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ render
+int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                  int32_t max_depth, uint64_t /*seed*/, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
+    if (!c) return FT_ERR_INVALID;
+    if (!cam || !jitter_xy || res_h < 2 || res_v < 2 || spp < 1 || max_depth < 0 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
+    if (max_depth > ftk::kMaxBounce) { c->err = "max_depth above 16"; return FT_ERR_UNSUPPORTED; }
+    if ((int64_t)res_h * res_v > (int64_t)0x7FFFFFFF) { c->err = "resolution too large"; return FT_ERR_INVALID; }
+    if (!need_device(c)) return FT_ERR_NO_DEVICE;
+    if (!c->committed) { c->err = "scene not committed (ft_scene_commit)"; return FT_ERR_STATE; }
+    if (cam->has_focus) { c->err = "camera focus (depth of field, Image.fs:91-94) is not on the device path yet"; return FT_ERR_UNSUPPORTED; }
+    const auto wall0 = std::chrono::steady_clock::now();
+    FT_HIP(c, hipSetDevice(c->device));
+
+    // pixel list (y-major, x: Image.fs:104) restricted to the tiles
+    std::vector<uint32_t> pixels;
+    const bool whole = tiles == nullptr;
+    int64_t n_pix_total = (int64_t)res_h * res_v;
+    if (!whole) {
+        for (int k = 0; k < n_tiles; ++k)
+            for (int y = tiles[k].y0; y < tiles[k].y0 + tiles[k].h; ++y)
+                for (int x = tiles[k].x0; x < tiles[k].x0 + tiles[k].w; ++x)
+                    if (x >= 0 && x < res_h && y >= 0 && y < res_v) pixels.push_back((uint32_t)(y * res_h + x));
+        n_pix_total = (int64_t)pixels.size();
+    }
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n_pix_total == 0) return FT_OK;
+
+    int32_t rc;
+    const int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, c->chunk_samples / spp));
+    const int64_t cap = pix_per_chunk * spp;
+    if (cap > 0x7FFFFFFFll) { c->err = "chunk too large"; return FT_ERR_INVALID; }
+    if ((rc = ensure_frame_buffers(c, cap)) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_out, (size_t)n_pix_total * 24)) != FT_OK) return rc;
+    if (!whole) { if ((rc = upload(c, c->d_pixels, pixels)) != FT_OK) return rc; }
+    std::vector<double> jit(jitter_xy, jitter_xy + 2 * (size_t)spp);
+    if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
+    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
+
+    const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
+    const size_t lds = lds_bytes_for(c->flat);
+    ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds), lds};
+    ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds), lds};
+    ftk::Launch Lg{c->stream, c->n_cu * 8, 0};
+    const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned
+    ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
+    ftk::HitBuf hb{c->d_hits.as<double>(), reinterpret_cast<uint32_t*>(c->d_hits.as<double>() + c->ray_capacity),
+                   reinterpret_cast<uint32_t*>(c->d_hits.as<double>() + c->ray_capacity) + c->ray_capacity};
+    auto* cc = c->d_cc.as<ftk::ChunkCounters>();
+    auto* rcount = c->d_rc.as<ftk::RenderCounters>();
+
+    c->events_used = 0;
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    auto timed = [&](int kind, auto&& fn) {
+        hipEvent_t a = next_event(c), b = next_event(c);
+        if (a) (void)hipEventRecord(a, c->stream);
+        fn();
+        if (b) (void)hipEventRecord(b, c->stream);
+        if (a && b) spans.push_back({a, b, kind});
+    };
+    hipEvent_t ev0 = next_event(c), ev1 = next_event(c);
+    if (ev0) (void)hipEventRecord(ev0, c->stream);
+    int n_chunks = 0, n_launches = 0;
+    for (int64_t p0 = 0; p0 < n_pix_total; p0 += pix_per_chunk, ++n_chunks) {
+        const uint32_t n_pix = (uint32_t)std::min<int64_t>(pix_per_chunk, n_pix_total - p0);
+        const uint32_t n_samples = n_pix * (uint32_t)spp;
+        FT_HIP(c, hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream));
+        timed(0, [&] { ftk::launch_generate(Lg, dcam, whole ? nullptr : c->d_pixels.as<uint32_t>(), (uint32_t)p0, n_pix, spp, c->d_jitter.as<double>(), rb[0], c->d_acc.as<double>(), cc); });
+        ++n_launches;
+        for (int b = 0; b <= last_bounce; ++b) {
+            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), b, cc, rcount); });
+            timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
+            n_launches += 2;
+        }
+        timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, c->d_out.as<double>() + 3 * p0); });
+        ++n_launches;
+    }
+    if (ev1) (void)hipEventRecord(ev1, c->stream);
+    FT_HIP(c, hipGetLastError());
+    FT_HIP(c, hipStreamSynchronize(c->stream));
+
+    ftk::RenderCounters hrc{};
+    FT_HIP(c, hipMemcpy(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost));
+    c->last_pixels = whole ? std::vector<uint32_t>() : pixels;
+    c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v;
+    if (out_rgb) { int32_t frc = ft_fetch_frame(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
+    for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+    for (auto& s : spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; } }
+    if (stats) {
+        float ms = 0;
+        if (ev0 && ev1) (void)hipEventElapsedTime(&ms, ev0, ev1);
+        stats->rays_primary = (uint64_t)n_pix_total * (uint64_t)spp;
+        stats->rays_shadow = hrc.rays_shadow; stats->rays_reflect = hrc.rays_reflect;
+        stats->rays_traced = stats->rays_primary + stats->rays_shadow + stats->rays_reflect;
+        stats->rays_reference_equivalent = (double)stats->rays_primary + hrc.ref_equiv;
+        stats->hits_primary = hrc.hits_primary; stats->csg_overflow = hrc.csg_overflow;
+        stats->kernel_ms = ms; stats->trace_kernel_ms = c->k_ms[1] + c->k_ms[2];
+        stats->algorithmic_bytes = (2 * ftk::kRayRecBytes + 2 * ftk::kHitRecBytes) * stats->rays_traced + 24ull * (uint64_t)n_pix_total;
+        stats->n_launches = n_launches; stats->n_chunks = n_chunks;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    if (hrc.csg_overflow) {
+        c->err = "CSG hit list overflow on " + std::to_string(hrc.csg_overflow) + " rays: raise csg_mesh_capacity (ft_set_option)";
+        return FT_ERR_OVERFLOW;
+    }
+    return FT_OK;
+}
+
+int32_t ft_get_kernel_times(ft_context* c, double ms[4], int32_t launches[4]) {
+    if (!c || !ms || !launches) return FT_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
+    return FT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ debug / tests
+int32_t ft_debug_closest(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t* hit, double* t, double* p, double* nrm, double* colour) {
+    if (!c || !origins || !dirs || n < 0 || !hit || !t || !p || !nrm || !colour) return FT_ERR_INVALID;
+    if (!need_device(c)) return FT_ERR_NO_DEVICE;
+    if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }
+    if (n == 0) return FT_OK;
+    FT_HIP(c, hipSetDevice(c->device));
+    int32_t rc;
+    const size_t N = (size_t)n;
+    if ((rc = ensure(c, c->d_dbg_in, N * 48)) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_dbg_out, N * (4 + 8 + 72))) != FT_OK) return rc;
+    double* din = c->d_dbg_in.as<double>();
+    FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
+    FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
+    double* dt = c->d_dbg_out.as<double>();
+    double* dp = dt + N; double* dn = dp + 3 * N; double* dc = dn + 3 * N;
+    int32_t* dh = reinterpret_cast<int32_t*>(dc + 3 * N);
+    const size_t lds = lds_bytes_for(c->flat);
+    ftk::Launch L{c->stream, c->n_cu * 4, lds};
+    ftk::launch_debug_closest(L, c->dev_scene, din, din + 3 * N, (uint32_t)n, dh, dt, dp, dn, dc, c->d_rc.as<ftk::RenderCounters>());
+    FT_HIP(c, hipGetLastError());
+    FT_HIP(c, hipMemcpyAsync(t, dt, N * 8, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipMemcpyAsync(p, dp, N * 24, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipMemcpyAsync(nrm, dn, N * 24, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipMemcpyAsync(colour, dc, N * 24, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipMemcpyAsync(hit, dh, N * 4, hipMemcpyDeviceToHost, c->stream));
+    ftk::RenderCounters hrc{};
+    FT_HIP(c, hipMemcpyAsync(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipStreamSynchronize(c->stream));
+    if (hrc.csg_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
+    return FT_OK;
+}
+
+int32_t ft_debug_blocked(ft_context* c, const double* origins, const double* dirs, const double* max_dist, int64_t n, int32_t* blocked) {
+    if (!c || !origins || !dirs || !max_dist || n < 0 || !blocked) return FT_ERR_INVALID;
+    if (!need_device(c)) return FT_ERR_NO_DEVICE;
+    if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }
+    if (n == 0) return FT_OK;
+    FT_HIP(c, hipSetDevice(c->device));
+    int32_t rc;
+    const size_t N = (size_t)n;
+    if ((rc = ensure(c, c->d_dbg_in, N * 56)) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_dbg_out, N * 4)) != FT_OK) return rc;
+    double* din = c->d_dbg_in.as<double>();
+    FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
+    FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
+    FT_HIP(c, hipMemcpyAsync(din + 6 * N, max_dist, N * 8, hipMemcpyHostToDevice, c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
+    const size_t lds = lds_bytes_for(c->flat);
+    ftk::Launch L{c->stream, c->n_cu * 4, lds};
+    ftk::launch_debug_blocked(L, c->dev_scene, din, din + 3 * N, din + 6 * N, (uint32_t)n, c->d_dbg_out.as<int32_t>(), c->d_rc.as<ftk::RenderCounters>());
+    FT_HIP(c, hipGetLastError());
+    FT_HIP(c, hipMemcpyAsync(blocked, c->d_dbg_out.p, N * 4, hipMemcpyDeviceToHost, c->stream));
+    ftk::RenderCounters hrc{};
+    FT_HIP(c, hipMemcpyAsync(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipStreamSynchronize(c->stream));
+    if (hrc.csg_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
+    return FT_OK;
+}
+
+int32_t ft_debug_scene_info(ft_context* c, int64_t out[8]) {
+    if (!c || !out) return FT_ERR_INVALID;
+    if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }
+    const fth::FlatScene& f = c->flat;
+    out[0] = (int64_t)f.leaves.size(); out[1] = (int64_t)f.program.size(); out[2] = (int64_t)f.meshes.size(); out[3] = (int64_t)f.nodes.size();
+    out[4] = (int64_t)f.bsp_leaves.size(); out[5] = (int64_t)(f.tris.size() / 9); out[6] = f.csg_capacity; out[7] = f.stack_capacity;
+    return FT_OK;
+}
+
+int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9], double above[18], int32_t* n_above, double below[18], int32_t* n_below) {
+    if (!p0 || !n || !tri || !above || !below || !n_above || !n_below) return FT_ERR_INVALID;
+    std::vector<double> a, b; std::string err;
+    int32_t rc = fth::slice_triangle(p0, n, tri, a, b, err);
+    if (rc != FT_OK) return rc;
+    *n_above = (int32_t)(a.size() / 9); *n_below = (int32_t)(b.size() / 9);
+    std::memcpy(above, a.data(), a.size() * 8); std::memcpy(below, b.data(), b.size() * 8);
+    return FT_OK;
+}
+
+int32_t ft_quantise_rgba8(const double* rgb, int64_t n_pixels, uint8_t* out) {   // Image.fs:36, Math.fs:12-16
+    if (!rgb || !out || n_pixels < 0) return FT_ERR_INVALID;
+    for (int64_t i = 0; i < n_pixels; ++i) {
+        for (int k = 0; k < 3; ++k) {
+            double x = rgb[3 * i + k];
+            if (x > 1.0) x = 1.0; else if (x < 0.0) x = 0.0;                     // NaN passes through the clamp unchanged
+            x = x * 255.0;
+            out[4 * i + k] = (x != x) ? 0 : (uint8_t)x;                          // truncation, not rounding
+        }
+        out[4 * i + 3] = 255;
+    }
+    return FT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,78 @@
+// ft_device.h — device-side buffer descriptors and the host-callable launch interface of
+// ft_kernels.hip.  Included by the C-ABI layer (ft_capi.cpp); contains no HIP device code.
+#ifndef FT_DEVICE_H
+#define FT_DEVICE_H
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "ft_flat.h"
+
+namespace ftk {
+
+constexpr int kBlock = 256;        // 4 wavefronts of 64; waves never synchronise with each other
+constexpr int kMaxBounce = 16;     // recursion limits above this are rejected by ft_render
+
+struct DevScene {
+    const double* leaves;          // n_leaves x 16 doubles (ftd::Leaf)
+    const double* m2w;             // n_leaves x 12
+    const ftd::Material* materials;
+    const ftd::Light* lights;
+    const uint32_t* program;
+    const ftd::Mesh* meshes;
+    const ftd::BspNode* nodes;
+    const ftd::BspLeaf* bsp_leaves;
+    const double* tris;            // 9 per triangle: v0, e1, e2
+    int32_t n_leaves, n_lights, csg_cap, stack_cap;
+};
+
+// Ray wavefront buffer, struct-of-arrays so a wave's 64 records are 512 contiguous bytes per field.
+// sizeof(RayRec) = 7*8 + 4 = 60 bytes; HitRec = 8 + 4 + 4 = 16 bytes (roofline).
+struct RayBuf { double *ox, *oy, *oz, *dx, *dy, *dz, *w; uint32_t* slot; };
+struct HitBuf { double* t; uint32_t* id0; uint32_t* id1; };
+constexpr uint64_t kRayRecBytes = 60, kHitRecBytes = 16;
+
+// Per-chunk device counters (zeroed before every chunk).
+struct ChunkCounters {
+    uint32_t n_rays[kMaxBounce + 2];   // rays queued for bounce k
+    uint32_t n_hits[kMaxBounce + 2];   // compacted lit/unlit hit count of bounce k
+    uint32_t work_trace[kMaxBounce + 2]; // work-stealing cursors
+    uint32_t work_shade[kMaxBounce + 2];
+};
+// Per-render device statistics (zeroed before every render).
+struct RenderCounters {
+    unsigned long long rays_shadow, rays_reflect, hits_primary, csg_overflow;
+    double ref_equiv;
+    double pad;
+};
+
+struct Camera {                    // ImagePlane (Image.fs:55-63), computed on the host
+    double o[3], k[3], i[3], j[3];
+    double pw, ph, tlx, tly;
+    int32_t res_h, res_v;
+};
+
+struct Launch {
+    hipStream_t stream;
+    int grid;                      // persistent grid size (workgroups)
+    size_t lds_bytes;
+};
+
+// K1: primary rays for chunk pixels [0,n_pix) x spp, slot = s*n_pix + pix; zeroes the accumulators.
+void launch_generate(const Launch& L, const Camera& cam, const uint32_t* pixel_ids, uint32_t pix_base, uint32_t n_pix,
+                     int32_t spp, const double* jitter, RayBuf rays, double* acc, ChunkCounters* cc);
+// K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.
+void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce,
+                    ChunkCounters* cc, RenderCounters* rc);
+// K3: shading + shadow rays + accumulation for the compacted hits of bounce k; emits bounce k+1 rays.
+void launch_shade(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
+                  double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
+// K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
+void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, double* out_rgb /* packed n_pix x 3 */);
+// Debug: closest hit / blocked for arbitrary rays (no slightOffset).
+void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,
+                          int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc);
+void launch_debug_blocked(const Launch& L, const DevScene& S, const double* o, const double* d, const double* max_dist,
+                          uint32_t n, int32_t* blocked, RenderCounters* rc);
+
+} // namespace ftk
+#endif

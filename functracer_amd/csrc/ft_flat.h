@@ -1,0 +1,97 @@
+// ft_flat.h — the flat, HBM-resident scene representation shared by the host flattener
+// (ft_scene.cpp) and the gfx950 kernels (ft_kernels.hip).  DESIGN.md §"Data layout in HBM".
+//
+// The reference evaluates a tree of closures per ray (Scene.fs:67-104).  Here the tree is
+// compiled once, on the host, into
+//   * leaves:   one per primitive INSTANCE with the world->model / model->world matrices of all
+//               enclosing Transform nodes pre-composed (Transform.fs:80-87; t is invariant under
+//               them), the flipNormals parity and the statically resolved material;
+//   * a program: a linear post-order instruction stream over the leaves that reproduces
+//               Ray.group concatenation order (Ray.fs:34) and Csg.constructedSolid (Csg.fs:74-94);
+//   * meshes:   clipped triangles + BSP nodes exactly as BspMesh.compile builds them
+//               (BspMesh.fs:51-65).
+// Everything a wavefront reads while tracing is wave-uniform and is fetched with scalar loads.
+#ifndef FT_FLAT_H
+#define FT_FLAT_H
+#include <stdint.h>
+
+namespace ftd {
+
+enum LeafKind : uint32_t {
+    LK_SPHERE = 0,    // Sphere.fs:11-21
+    LK_PLANE = 1,     // Plane.fs:28-33
+    LK_SQUARE = 2,    // Cube.fs:9-15
+    LK_CIRCLE = 3,    // Cylinder.fs:22
+    LK_CUBE = 4,      // Cube.fs:17-25 (six squares, evaluated in the cube's own frame)
+    LK_CONE = 5,      // Cone.fs:7-27
+    LK_CYLINDER = 6,  // Cylinder.fs:8-20
+    LK_SOLIDCYL = 7,  // Cylinder.fs:25-29 (top disc, bottom disc, sides)
+    LK_MESH = 8       // BspMesh.fs:67-76, 95-97; also single Triangle primitives (Triangle.fs:43-66)
+};
+
+enum LeafFlags : uint32_t {
+    LF_FLIP = 1u,          // odd number of flipNormals on the path (Ray.fs:36)
+    LF_XFORM = 2u,         // at least one Transform node encloses the leaf (normal is re-normalised, Transform.fs:86)
+    LF_LIT = 4u            // material.applyLighting (casts shadows, Scene.fs:121)
+};
+
+// 128 bytes; array element i lives at leaf_w2m + 16*i doubles.
+struct Leaf {
+    double w2m[12];        // rows of the 3x4 world->model matrix
+    uint32_t kind;
+    uint32_t flags;
+    uint32_t material;
+    uint32_t mesh;         // index into meshes[] for LK_MESH
+    uint32_t pad[4];
+};
+
+struct Material {          // Ray.fs:4-10; 64 bytes
+    double colour[3];
+    double roughness, reflectance, shineyness;
+    uint32_t apply_lighting;
+    int32_t texture;       // -1 = none
+    uint32_t hue_rot;      // number of hueShift channel rotations applied after the colour source (Ray.fs:51-55)
+    uint32_t pad;
+};
+
+enum LightKind : uint32_t { LT_DIRECTIONAL = 0, LT_SOFT = 1, LT_POINT = 2 };
+struct Light {             // Light.fs:7-14; 96 bytes
+    double v[3];           // normalised direction | position
+    double falloff[3];
+    double colour[3];
+    double scatter;
+    uint32_t kind;
+    int32_t samples;
+    double pad;
+};
+
+struct Mesh {
+    int32_t root;          // >= 0: BSP branch node index; < 0: ~leaf index (top-level Leaf, brute force, no AABB)
+    uint32_t n_source_tris;
+    uint32_t max_depth;    // BspMesh.maxDepth of the compiled tree
+    uint32_t pad;
+};
+struct BspNode {           // 64 bytes; BspMesh.fs:12-19
+    double bmin[3], bmax[3];
+    int32_t left, right;   // >= 0 branch node; < 0: ~leaf index
+    uint32_t pad[2];
+};
+struct BspLeaf { uint32_t first_tri, n_tris; };
+// Triangles: 9 doubles each = v0, edge1 = v1 - v0, edge2 = v2 - v0 (Triangle.fs:45-46 evaluated once on the host).
+
+// Program words: opcode in the low 8 bits, argument in the high 24.
+enum Op : uint32_t {
+    OP_END = 0,
+    OP_LEAF_FOLD = 1,      // intersect leaf, fold every hit straight into the running closest / any-hit
+    OP_LEAF_PUSH = 2,      // intersect leaf, append hits to the per-lane hit list (inside a CSG subtree)
+    OP_MARK = 3,           // push the current list length (start of an operand segment)
+    OP_CSG = 4,            // merge the two topmost segments with rule table arg (ft_csg_op)
+    OP_FOLD_LIST = 5       // fold the per-lane list into closest / any-hit and clear it
+};
+inline uint32_t make_op(uint32_t op, uint32_t arg) { return op | (arg << 8); }
+
+// Hit identity: id0 = leaf | sub << 24 | flip << 30 | sideB << 31 (sideB only while sorting); id1 = triangle index.
+enum : uint32_t { ID_LEAF_MASK = 0x00FFFFFFu, ID_SUB_SHIFT = 24, ID_SUB_MASK = 0x7u, ID_FLIP = 1u << 30, ID_SIDE_B = 1u << 31, ID_MISS = 0xFFFFFFFFu };
+
+} // namespace ftd
+#endif

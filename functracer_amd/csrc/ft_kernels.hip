@@ -1,0 +1,716 @@
+// ft_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the FuncTracer render loop.
+//
+// Pipeline per chunk of samples (DESIGN.md §"Kernels"):
+//   k_generate  primary rays        Image.fs:83-89, 100-110
+//   k_closest   closest hit         Scene.fs:112-118 over the flattened Scene.intersect (Scene.fs:67-104)
+//   k_shade     Phong + shadow rays + reflection spawn   Shading.fs:24-139
+//   k_blend     per-pixel mean      Image.fs:112-116
+// k_closest / k_shade run once per bounce on wavefront ray buffers in HBM; rays that terminate
+// are dropped by wave-ballot / prefix-sum compaction, so every lane of the next stage is live.
+// All kernels use persistent grids whose waves pull 64-ray batches from an atomic cursor.
+//
+// Execution model notes (wave64, CDNA4):
+//   * one lane = one ray; the scene program, leaf records, matrices, materials, lights and
+//     brute-force triangle lists are wave-uniform and are read with scalar loads (SGPR operands);
+//   * FP64 throughout (the reference is F# float); no MFMA — this is branchy scalar geometry;
+//   * per-lane CSG hit lists and BSP node stacks live in LDS, laid out [entry][lane] so that a
+//     wave access is always bank-conflict free whatever entry each lane touches;
+//   * waves are independent: no __syncthreads anywhere.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ft_device.h"
+
+using namespace ftd;
+
+namespace ftk {
+namespace {
+
+#define FT_DEV __device__ __forceinline__
+
+constexpr double kEps = 0.0000001;
+constexpr int kDone = INT32_MIN;
+
+struct Ray { double ox, oy, oz, dx, dy, dz; };
+struct V3 { double x, y, z; };
+
+FT_DEV double dot3(double ax, double ay, double az, double bx, double by, double bz) { return ax * bx + ay * by + az * bz; }
+FT_DEV V3 normalise(V3 v) {                                       // CommonTypes.fs:63-67
+    double l = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (l < kEps) return v;
+    double s = 1.0 / l;
+    return {s * v.x, s * v.y, s * v.z};
+}
+FT_DEV double fs_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? b : a); }  // F# max on float = Math.Max
+FT_DEV double fs_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
+
+FT_DEV uint32_t lane_id() { return __lane_id(); }
+FT_DEV uint32_t lanes_below(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
+
+// ---------------------------------------------------------------------------------------------
+// Per-lane hit list in LDS (only used under CSG nodes).  Entry e, word w of this lane lives at
+// base[(e*4 + w) * kBlock]: consecutive lanes hit consecutive banks for every (e, w).
+struct HitList {
+    uint32_t* base;
+    int len;
+    int cap;
+    unsigned long long marks_lo, marks_hi;
+    bool overflow;
+
+    FT_DEV void init(uint32_t* lds, int capacity) { base = lds + threadIdx.x; len = 0; cap = capacity; marks_lo = marks_hi = 0; overflow = false; }
+    FT_DEV void store(int e, double t, uint32_t id0, uint32_t id1) {
+        unsigned long long b = __double_as_longlong(t);
+        base[(e * 4 + 0) * kBlock] = (uint32_t)b; base[(e * 4 + 1) * kBlock] = (uint32_t)(b >> 32);
+        base[(e * 4 + 2) * kBlock] = id0; base[(e * 4 + 3) * kBlock] = id1;
+    }
+    FT_DEV double t_of(int e) const {
+        unsigned long long b = (unsigned long long)base[(e * 4 + 0) * kBlock] | ((unsigned long long)base[(e * 4 + 1) * kBlock] << 32);
+        return __longlong_as_double(b);
+    }
+    FT_DEV uint32_t id0_of(int e) const { return base[(e * 4 + 2) * kBlock]; }
+    FT_DEV uint32_t id1_of(int e) const { return base[(e * 4 + 3) * kBlock]; }
+    FT_DEV void set_id0(int e, uint32_t v) { base[(e * 4 + 2) * kBlock] = v; }
+    FT_DEV void push(double t, uint32_t id0, uint32_t id1) {
+        if (len < cap) { store(len, t, id0, id1); ++len; } else overflow = true;   // never silently dropped: reported via RenderCounters
+    }
+    FT_DEV void mark() { marks_hi = (marks_hi << 8) | (marks_lo >> 56); marks_lo = (marks_lo << 8) | (unsigned long long)(uint32_t)len; }
+    FT_DEV int pop_mark() { int m = (int)(marks_lo & 0xFF); marks_lo = (marks_lo >> 8) | (marks_hi << 56); marks_hi >>= 8; return m; }
+};
+
+// Csg.constructedSolid (Csg.fs:74-94) on the two topmost segments of the lane's list.
+// Rule tables (Csg.fs:19-55) as bit masks over IntersectionType
+//   0 OutsideIntoA 1 OutsideIntoB 2 BIntoAB 3 AIntoAB 4 ABleaveA 5 ABleaveB 6 AIntoOutside 7 BIntoOutside
+FT_DEV void csg_merge(HitList& L, uint32_t op) {
+    const int seg_b = L.pop_mark();
+    const int seg_a = L.pop_mark();
+    const int end = L.len;
+    if (!__any(end > seg_a)) return;                               // no lane has anything to merge
+    uint32_t take, flip;
+    switch (op) {                                                   // wave-uniform
+        case 0: take = 0xC3u; flip = 0x00u; break;                 // union
+        case 1: take = 0x3Cu; flip = 0x00u; break;                 // intersect
+        case 2: take = 0x41u; flip = 0x28u; break;                 // subtract
+        default: take = 0xC3u; flip = 0x3Cu; break;                 // exclude
+    }
+    for (int e = seg_b; e < end; ++e) L.set_id0(e, L.id0_of(e) | ID_SIDE_B);       // HitB tag (Csg.fs:77)
+    for (int i = seg_a + 1; i < end; ++i) {                         // stable insertion sort by t (Seq.sortBy, Csg.fs:78-79)
+        const double kt = L.t_of(i); const uint32_t k0 = L.id0_of(i), k1 = L.id1_of(i);
+        int j = i;
+        while (j > seg_a && kt < L.t_of(j - 1)) { L.store(j, L.t_of(j - 1), L.id0_of(j - 1), L.id1_of(j - 1)); --j; }
+        if (j != i) L.store(j, kt, k0, k1);
+    }
+    bool in_a = false, in_b = false;
+    int w = seg_a;
+    for (int r = seg_a; r < end; ++r) {                             // iterate (Csg.fs:81-93)
+        const double t = L.t_of(r); uint32_t id0 = L.id0_of(r); const uint32_t id1 = L.id1_of(r);
+        const bool side_b = (id0 & ID_SIDE_B) != 0;
+        // getIntersectionType (Csg.fs:59-72): index = sideB*4 + inA*2 + inB
+        const uint32_t type = (0x53714620u >> (4 * ((side_b ? 4 : 0) + (in_a ? 2 : 0) + (in_b ? 1 : 0)))) & 0xF;
+        if (side_b) in_b = !in_b; else in_a = !in_a;
+        id0 &= ~ID_SIDE_B;
+        if ((flip >> type) & 1u) id0 ^= ID_FLIP;                    // Flip: n <- -1.0 * n
+        if (((take | flip) >> type) & 1u) { L.store(w, t, id0, id1); ++w; }
+    }
+    L.len = w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Running result of a scene query.  ANY = lightIsBocked (Scene.fs:119-121), else closest (Scene.fs:112-116):
+// hits arrive in the reference's sequence order, so "strictly smaller t wins" reproduces
+// stable-sort-then-head, t = 0 (and -0) is kept, negatives are skipped.
+template <bool ANY>
+struct Query {
+    double best_t; uint32_t id0, id1;
+    double max_dist; bool blocked;
+    bool active;
+    FT_DEV void hit(double t, uint32_t i0, uint32_t i1, bool lit) {
+        if (!active) return;
+        if (ANY) { if (t >= 0.0 && t < max_dist && lit) blocked = true; }
+        else { if (t >= 0.0 && t < best_t) { best_t = t; id0 = i0; id1 = i1; } }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Leaf intersection.  `emit(t, sub, tri)` is called once per hit in the reference's order.
+
+// Plane.intersect with the canonical plane (Plane.fs:9-20, 28-33) given num = (p0-o).n, den = d.n.
+FT_DEV bool plane_t(double num, double den, double& t) {
+    if (fabs(den) < kEps) { t = 0.0; return num < kEps; }          // parallel ray: hit at the origin iff on/above
+    t = num / den;
+    return true;
+}
+
+// Möller–Trumbore (Triangle.fs:43-66) against v0,e1,e2.  The u / v range tests are decided without the
+// division whenever the outcome cannot depend on its rounding; the surviving lanes run the
+// reference's exact sequence.
+FT_DEV bool tri_hit(const double* __restrict__ T, const Ray& r, double& t_out) {
+    const double v0x = T[0], v0y = T[1], v0z = T[2], e1x = T[3], e1y = T[4], e1z = T[5], e2x = T[6], e2y = T[7], e2z = T[8];
+    const double hx = r.dy * e2z - r.dz * e2y, hy = e2x * r.dz - e2z * r.dx, hz = r.dx * e2y - r.dy * e2x;   // ray.d .** edge2
+    const double a = e1x * hx + e1y * hy + e1z * hz;
+    if (a > -kEps && a < kEps) return false;
+    const double sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
+    const double sh = sx * hx + sy * hy + sz * hz;
+    const double abs_a = fabs(a);
+    // u = (1/a)*sh: u < 0 iff sh and a have strictly opposite signs; |sh| > |a|(1+4e-15) implies fl(u) > 1.
+    if ((sh < 0.0 && a > 0.0) || (sh > 0.0 && a < 0.0) || fabs(sh) > abs_a * 1.000000000000004) return false;
+    const double qx = sy * e1z - sz * e1y, qy = e1x * sz - e1z * sx, qz = sx * e1y - sy * e1x;               // s .** edge1
+    const double dq = r.dx * qx + r.dy * qy + r.dz * qz;
+    if ((dq < 0.0 && a > 0.0) || (dq > 0.0 && a < 0.0) || fabs(dq) > abs_a * 1.000000000000004) return false;
+    const double f = 1.0 / a;
+    const double u = f * sh;
+    if (u < 0.0 || u > 1.0) return false;
+    const double v = f * dq;
+    if (v < 0.0 || u + v > 1.0) return false;
+    const double t = f * (e2x * qx + e2y * qy + e2z * qz);
+    if (t > kEps) { t_out = t; return true; }
+    return false;
+}
+
+// BoundingBox.intersects (BoundingBox.fs:32-58), inverse direction precomputed per ray.
+FT_DEV bool aabb_hit(const BspNode& n, const Ray& r, double ivx, double ivy, double ivz) {
+    const bool nx = ivx < 0.0, ny = ivy < 0.0, nz = ivz < 0.0;
+    double tmin = ((nx ? n.bmax[0] : n.bmin[0]) - r.ox) * ivx;
+    double tmax = ((nx ? n.bmin[0] : n.bmax[0]) - r.ox) * ivx;
+    const double tymin = ((ny ? n.bmax[1] : n.bmin[1]) - r.oy) * ivy;
+    const double tymax = ((ny ? n.bmin[1] : n.bmax[1]) - r.oy) * ivy;
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    tmin = fs_max(tymin, tmin);
+    tmax = fs_min(tymax, tmax);
+    const double tzmin = ((nz ? n.bmax[2] : n.bmin[2]) - r.oz) * ivz;
+    const double tzmax = ((nz ? n.bmin[2] : n.bmax[2]) - r.oz) * ivz;
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    tmin = fs_max(tzmin, tmin);
+    tmax = fs_min(tzmax, tmax);
+    return (tmin < __builtin_inf()) && (tmax > -__builtin_inf());
+}
+
+template <class Emit>
+FT_DEV void mesh_hits(const DevScene& S, uint32_t mesh_idx, const Ray& r, bool active, int32_t* stack, Emit&& emit) {
+    const Mesh mesh = S.meshes[mesh_idx];
+    if (mesh.root < 0) {                                           // top-level Leaf: brute force, no AABB (BspMesh.fs:95-97)
+        const BspLeaf lf = S.bsp_leaves[~mesh.root];
+        const double* __restrict__ T = S.tris + 9ull * lf.first_tri;
+        for (uint32_t k = 0; k < lf.n_tris; ++k, T += 9) {         // wave-uniform loop: triangle data comes through scalar loads
+            double t;
+            if (tri_hit(T, r, t)) emit(t, 0u, lf.first_tri + k);
+        }
+        return;
+    }
+    // BspMesh.intersect (BspMesh.fs:67-76): at a branch whose box the ray's line meets, all hits of the
+    // RIGHT child come before those of the LEFT child.  Per-lane DFS with the pending left children on an
+    // LDS stack.
+    const double ivx = 1.0 / r.dx, ivy = 1.0 / r.dy, ivz = 1.0 / r.dz;
+    int sp = 0;
+    int cur = active ? mesh.root : kDone;
+    while (__any(cur != kDone)) {
+        while (cur >= 0) {                                         // descend through branches
+            const BspNode& n = S.nodes[cur];
+            if (aabb_hit(n, r, ivx, ivy, ivz)) { stack[sp * kBlock] = n.left; ++sp; cur = n.right; }
+            else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+            else cur = kDone;
+        }
+        if (cur != kDone) {                                        // a leaf: every triangle, in list order
+            const BspLeaf lf = S.bsp_leaves[~cur];
+            for (uint32_t k = 0; k < lf.n_tris; ++k) {
+                double t;
+                if (tri_hit(S.tris + 9ull * (lf.first_tri + k), r, t)) emit(t, 0u, lf.first_tri + k);
+            }
+            if (sp > 0) { --sp; cur = stack[sp * kBlock]; } else cur = kDone;
+        }
+    }
+}
+
+FT_DEV void to_model(const double* __restrict__ M, bool xform, const Ray& r, Ray& m) {   // Transform.fs:85
+    if (xform) {
+        m.ox = M[0] * r.ox + M[1] * r.oy + M[2] * r.oz + M[3];
+        m.oy = M[4] * r.ox + M[5] * r.oy + M[6] * r.oz + M[7];
+        m.oz = M[8] * r.ox + M[9] * r.oy + M[10] * r.oz + M[11];
+        m.dx = M[0] * r.dx + M[1] * r.dy + M[2] * r.dz;
+        m.dy = M[4] * r.dx + M[5] * r.dy + M[6] * r.dz;
+        m.dz = M[8] * r.dx + M[9] * r.dy + M[10] * r.dz;
+    } else m = r;
+}
+
+struct LeafHead { uint32_t kind, flags, material, mesh; };
+FT_DEV LeafHead leaf_head(const DevScene& S, uint32_t leaf) {
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(S.leaves + 16ull * leaf + 12);
+    return {h[0], h[1], h[2], h[3]};
+}
+
+// Math.quadratic (Math.fs:4-10): far root first.
+FT_DEV bool quadratic(double a, double b, double c, double& r0, double& r1) {
+    const double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return false;
+    const double sq = sqrt(disc), twoa = 2.0 * a;
+    r0 = (-b + sq) / twoa; r1 = (-b - sq) / twoa;
+    return true;
+}
+
+template <class Emit>
+FT_DEV void leaf_hits(const DevScene& S, uint32_t leaf, const LeafHead& H, const Ray& rw, bool active, int32_t* stack, Emit&& emit) {
+    Ray r;
+    to_model(S.leaves + 16ull * leaf, (H.flags & LF_XFORM) != 0, rw, r);
+    switch (H.kind) {                                              // wave-uniform
+        case LK_SPHERE: {                                          // Sphere.fs:11-21
+            const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+            const double b = 2.0 * dot3(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+            const double c = dot3(r.ox, r.oy, r.oz, r.ox, r.oy, r.oz) - 1.0;
+            double t0, t1;
+            if (quadratic(a, b, c, t0, t1)) { emit(t0, 0u, 0u); emit(t1, 1u, 0u); }
+            break;
+        }
+        case LK_PLANE: {                                           // Plane.fs:28-33
+            double t;
+            if (plane_t(-r.oy, r.dy, t)) emit(t, 0u, 0u);
+            break;
+        }
+        case LK_SQUARE: {                                          // Cube.fs:9-15
+            double t;
+            if (plane_t(-r.oy, r.dy, t)) {
+                const double px = r.ox + t * r.dx, pz = r.oz + t * r.dz;
+                if (px >= 0.0 && px <= 1.0 && pz >= 0.0 && pz <= 1.0) emit(t, 0u, 0u);
+            }
+            break;
+        }
+        case LK_CIRCLE: {                                          // Cylinder.fs:22
+            double t;
+            if (plane_t(-r.oy, r.dy, t)) {
+                const double px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
+                if (sqrt(px * px + py * py + pz * pz) < 1.0) emit(t, 0u, 0u);
+            }
+            break;
+        }
+        case LK_CUBE: {                                            // Cube.fs:17-25, in the [0,1]^3 frame behind translate(-.5)
+            const double qx = r.ox + 0.5, qy = r.oy + 0.5, qz = r.oz + 0.5;
+            double t;
+            // bottom (y=0, flipped) and top (y=1): clip on x,z
+            if (plane_t(-qy, r.dy, t)) { const double u = qx + t * r.dx, v = qz + t * r.dz; if (u >= 0.0 && u <= 1.0 && v >= 0.0 && v <= 1.0) emit(t, 0u, 0u); }
+            if (plane_t(-(qy - 1.0), r.dy, t)) { const double u = qx + t * r.dx, v = qz + t * r.dz; if (u >= 0.0 && u <= 1.0 && v >= 0.0 && v <= 1.0) emit(t, 1u, 0u); }
+            // left (x=0) and right (x=1, flipped): local frame (y,-x,z), clip on y,z
+            if (plane_t(qx, -r.dx, t)) { const double u = qy + t * r.dy, v = qz + t * r.dz; if (u >= 0.0 && u <= 1.0 && v >= 0.0 && v <= 1.0) emit(t, 2u, 0u); }
+            if (plane_t(qx - 1.0, -r.dx, t)) { const double u = qy + t * r.dy, v = qz + t * r.dz; if (u >= 0.0 && u <= 1.0 && v >= 0.0 && v <= 1.0) emit(t, 3u, 0u); }
+            // front (z=0) and back (z=1, flipped): local frame (x,-z,y), clip on x,y
+            if (plane_t(qz, -r.dz, t)) { const double u = qx + t * r.dx, v = qy + t * r.dy; if (u >= 0.0 && u <= 1.0 && v >= 0.0 && v <= 1.0) emit(t, 4u, 0u); }
+            if (plane_t(qz - 1.0, -r.dz, t)) { const double u = qx + t * r.dx, v = qy + t * r.dy; if (u >= 0.0 && u <= 1.0 && v >= 0.0 && v <= 1.0) emit(t, 5u, 0u); }
+            break;
+        }
+        case LK_CONE: {                                            // Cone.fs:7-27
+            const double oy = r.oy - 1.0;
+            const double a = r.dx * r.dx + r.dz * r.dz - r.dy * r.dy;
+            const double b = 2.0 * (r.ox * r.dx + r.oz * r.dz - oy * r.dy);
+            const double c = r.ox * r.ox + r.oz * r.oz - oy * oy;
+            double t0, t1;
+            if (quadratic(a, b, c, t0, t1)) {
+                double py = (oy + t0 * r.dy) + 1.0; if (py >= 0.0 && py <= 1.0) emit(t0, 0u, 0u);
+                py = (oy + t1 * r.dy) + 1.0;        if (py >= 0.0 && py <= 1.0) emit(t1, 1u, 0u);
+            }
+            break;
+        }
+        case LK_CYLINDER: {                                        // Cylinder.fs:8-20
+            const double a = r.dx * r.dx + r.dz * r.dz;
+            const double b = 2.0 * (r.ox * r.dx + r.oz * r.dz);
+            const double c = r.ox * r.ox + r.oz * r.oz - 1.0;
+            double t0, t1;
+            if (quadratic(a, b, c, t0, t1)) {
+                double py = r.oy + t0 * r.dy; if (py >= 0.0 && py <= 1.0) emit(t0, 0u, 0u);
+                py = r.oy + t1 * r.dy;        if (py >= 0.0 && py <= 1.0) emit(t1, 1u, 0u);
+            }
+            break;
+        }
+        case LK_SOLIDCYL: {                                        // Cylinder.fs:25-29: [top; bottom; sides]
+            double t;
+            const double oyt = r.oy - 1.0;                         // top: translate (0,1,0) circle
+            if (plane_t(-oyt, r.dy, t)) { const double px = r.ox + t * r.dx, py = oyt + t * r.dy, pz = r.oz + t * r.dz; if (sqrt(px * px + py * py + pz * pz) < 1.0) emit(t, 0u, 0u); }
+            // bottom: rotate Z 180 circle — local frame (-x,-y,z)
+            if (plane_t(r.oy, -r.dy, t)) { const double px = -r.ox + t * -r.dx, py = -r.oy + t * -r.dy, pz = r.oz + t * r.dz; if (sqrt(px * px + py * py + pz * pz) < 1.0) emit(t, 1u, 0u); }
+            const double a = r.dx * r.dx + r.dz * r.dz;
+            const double b = 2.0 * (r.ox * r.dx + r.oz * r.dz);
+            const double c = r.ox * r.ox + r.oz * r.oz - 1.0;
+            double t0, t1;
+            if (quadratic(a, b, c, t0, t1)) {
+                double py = r.oy + t0 * r.dy; if (py >= 0.0 && py <= 1.0) emit(t0, 2u, 0u);
+                py = r.oy + t1 * r.dy;        if (py >= 0.0 && py <= 1.0) emit(t1, 3u, 0u);
+            }
+            break;
+        }
+        default:                                                   // LK_MESH
+            mesh_hits(S, H.mesh, r, active, stack, emit);
+            break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
+template <bool ANY>
+FT_DEV void trace(const DevScene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow) {
+    HitList L;
+    L.init(lds, S.csg_cap);
+    int32_t* stack = reinterpret_cast<int32_t*>(lds + 4 * S.csg_cap * kBlock) + threadIdx.x;
+    for (uint32_t pc = 0;; ++pc) {
+        const uint32_t ins = S.program[pc];                        // wave-uniform: scalar load
+        const uint32_t op = ins & 0xFFu, arg = ins >> 8;
+        if (op == OP_END) break;
+        switch (op) {
+            case OP_LEAF_FOLD: {
+                const LeafHead H = leaf_head(S, arg);
+                const bool lit = (H.flags & LF_LIT) != 0;
+                leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { q.hit(t, arg | (sub << ID_SUB_SHIFT), tri, lit); });
+                break;
+            }
+            case OP_LEAF_PUSH: {
+                const LeafHead H = leaf_head(S, arg);
+                leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { if (q.active) L.push(t, arg | (sub << ID_SUB_SHIFT), tri); });
+                break;
+            }
+            case OP_MARK: L.mark(); break;
+            case OP_CSG: csg_merge(L, arg); break;
+            default: {                                             // OP_FOLD_LIST
+                for (int e = 0; e < L.len; ++e) {
+                    const uint32_t id0 = L.id0_of(e);
+                    const LeafHead H = leaf_head(S, id0 & ID_LEAF_MASK);   // per-lane leaf: vector load
+                    q.hit(L.t_of(e), id0, L.id1_of(e), (H.flags & LF_LIT) != 0);
+                }
+                L.len = 0;
+                break;
+            }
+        }
+        if (ANY) { if (__all(q.blocked || !q.active)) break; }    // every lane already in shadow
+    }
+    overflow = L.overflow;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Surface point, normal and material of a closest hit (recomputed from t + hit identity; the
+// reference computes them for every candidate hit, the values for the winner are the same).
+struct Surface { V3 p, n; uint32_t material; };
+
+FT_DEV void cylinder_side(const Ray& r, double t, V3& p, V3& n) {   // Cylinder.fs:14-17
+    p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz};
+    const V3 nn = normalise(V3{p.x, 0.0, p.z});
+    n = (dot3(nn.x, nn.y, nn.z, r.dx, r.dy, r.dz) < 0.0) ? nn : V3{-nn.x, -nn.y, -nn.z};
+}
+
+FT_DEV Surface surface_at(const DevScene& S, const Ray& rw, double t, uint32_t id0, uint32_t id1) {
+    const uint32_t leaf = id0 & ID_LEAF_MASK, sub = (id0 >> ID_SUB_SHIFT) & ID_SUB_MASK;
+    const LeafHead H = leaf_head(S, leaf);
+    const double* __restrict__ M = S.leaves + 16ull * leaf;
+    const bool xform = (H.flags & LF_XFORM) != 0;
+    Ray r;
+    to_model(M, xform, rw, r);
+    V3 p, n;
+    switch (H.kind) {
+        case LK_SPHERE: p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = normalise(p); break;
+        case LK_PLANE: case LK_SQUARE: case LK_CIRCLE: p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = {0.0, 1.0, 0.0}; break;
+        case LK_CUBE: {
+            const double qx = r.ox + 0.5, qy = r.oy + 0.5, qz = r.oz + 0.5;
+            p = {(qx + t * r.dx) - 0.5, (qy + t * r.dy) - 0.5, (qz + t * r.dz) - 0.5};
+            n = {sub == 2 ? -1.0 : sub == 3 ? 1.0 : 0.0, sub == 0 ? -1.0 : sub == 1 ? 1.0 : 0.0, sub == 4 ? -1.0 : sub == 5 ? 1.0 : 0.0};
+            break;
+        }
+        case LK_CONE: {
+            const double oy = r.oy - 1.0;
+            const double qx = r.ox + t * r.dx, qy = oy + t * r.dy, qz = r.oz + t * r.dz;
+            p = {qx, qy + 1.0, qz};
+            const V3 nn = normalise(V3{qx, -qy, qz});
+            n = (dot3(nn.x, nn.y, nn.z, r.dx, r.dy, r.dz) < 0.0) ? nn : V3{-nn.x, -nn.y, -nn.z};
+            break;
+        }
+        case LK_CYLINDER: cylinder_side(r, t, p, n); break;
+        case LK_SOLIDCYL: {
+            if (sub >= 2) cylinder_side(r, t, p, n);
+            else if (sub == 0) { const double oyt = r.oy - 1.0; p = {r.ox + t * r.dx, (oyt + t * r.dy) + 1.0, r.oz + t * r.dz}; n = {0.0, 1.0, 0.0}; }
+            else { p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = {0.0, -1.0, 0.0}; }
+            break;
+        }
+        default: {                                                 // triangle (Triangle.fs:63-64)
+            const double* __restrict__ T = S.tris + 9ull * id1;
+            const double len = sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+            const V3 nd = normalise(V3{r.dx, r.dy, r.dz});
+            const double k = t * len;
+            p = {r.ox + nd.x * k, r.oy + nd.y * k, r.oz + nd.z * k};
+            n = normalise(V3{T[4] * T[8] - T[5] * T[7], T[6] * T[5] - T[8] * T[3], T[3] * T[7] - T[4] * T[6]});   // edge1 .** edge2
+            break;
+        }
+    }
+    if (xform) {                                                   // Transform.fs:86: p <- modelToWorld*p, n <- normalise(normalToWorld*n)
+        const double* __restrict__ W = S.m2w + 12ull * leaf;
+        p = {W[0] * p.x + W[1] * p.y + W[2] * p.z + W[3], W[4] * p.x + W[5] * p.y + W[6] * p.z + W[7], W[8] * p.x + W[9] * p.y + W[10] * p.z + W[11]};
+        n = normalise(V3{M[0] * n.x + M[4] * n.y + M[8] * n.z, M[1] * n.x + M[5] * n.y + M[9] * n.z, M[2] * n.x + M[6] * n.y + M[10] * n.z});   // (W2M^T) n
+    }
+    const bool flip = (((H.flags & LF_FLIP) != 0) != ((id0 & ID_FLIP) != 0));
+    if (flip) n = {-n.x, -n.y, -n.z};
+    return {p, n, H.material};
+}
+
+// Wave-cooperative grab of the next 64-item batch from a persistent work cursor.
+FT_DEV uint32_t grab_batch(uint32_t* cursor) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(cursor, 64u);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+FT_DEV void wave_add(unsigned long long* dst, unsigned long long v_per_lane_flag_count) {
+    // caller passes an already wave-reduced value from lane 0 only
+    if (lane_id() == 0 && v_per_lane_flag_count) atomicAdd(dst, v_per_lane_flag_count);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(Camera cam, const uint32_t* __restrict__ pixel_ids, uint32_t pix_base, uint32_t n_pix,
+                                                      int32_t spp, const double* __restrict__ jitter, RayBuf rays, double* __restrict__ acc, ChunkCounters* cc) {
+    const uint32_t n = n_pix * (uint32_t)spp;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t s = i / n_pix, pl = i - s * n_pix;          // slot = s*n_pix + pixel: adjacent lanes = adjacent pixels
+        const uint32_t pid = pixel_ids ? pixel_ids[pix_base + pl] : pix_base + pl;
+        const uint32_t py = pid / (uint32_t)cam.res_h, px = pid - py * (uint32_t)cam.res_h;
+        // ImagePlane.rayThroughPixel (Image.fs:83-89)
+        const double centre_x = cam.tlx + (double)px * cam.pw, centre_y = cam.tly - (double)py * cam.ph;
+        const double jx = centre_x + jitter[2 * s] * cam.pw, jy = centre_y + jitter[2 * s + 1] * cam.ph;
+        rays.ox[i] = cam.o[0]; rays.oy[i] = cam.o[1]; rays.oz[i] = cam.o[2];
+        rays.dx[i] = (cam.k[0] + jx * cam.i[0]) + jy * cam.j[0];
+        rays.dy[i] = (cam.k[1] + jx * cam.i[1]) + jy * cam.j[1];
+        rays.dz[i] = (cam.k[2] + jx * cam.i[2]) + jy * cam.j[2];
+        rays.w[i] = 1.0; rays.slot[i] = i;
+        acc[i] = 0.0; acc[(size_t)n + i] = 0.0; acc[2 * (size_t)n + i] = 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cc->n_rays[0] = n;
+}
+
+__global__ __launch_bounds__(kBlock) void k_closest(DevScene S, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
+                                                     ChunkCounters* cc, RenderCounters* rc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t n = cc->n_rays[bounce];
+    unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
+    for (;;) {
+        const uint32_t base = grab_batch(&cc->work_trace[bounce]);
+        if (base >= n) break;
+        const uint32_t i = base + lane_id();
+        Query<false> q;
+        q.active = i < n; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
+        Ray r{0, 0, 0, 0, 0, 0};
+        if (q.active) {
+            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
+            r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
+        }
+        bool overflow;
+        trace<false>(S, r, q, lds, overflow);
+        const bool hit = q.active && q.id0 != ID_MISS;
+        if (q.active) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }
+        // wave-ballot / prefix-sum compaction of the rays that hit
+        const unsigned long long m = __ballot(hit);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        uint32_t dst = 0;
+        if (lane_id() == 0 && cnt) dst = atomicAdd(&cc->n_hits[bounce], cnt);
+        dst = __builtin_amdgcn_readfirstlane(dst);
+        if (hit) hit_list[dst + lanes_below(m)] = i;
+        n_hit_wave += cnt;
+        n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
+    }
+    if (bounce == 0) wave_add(&rc->hits_primary, n_hit_wave);
+    wave_add(&rc->csg_overflow, n_ovf_wave);
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
+                                                   double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
+                                                   ChunkCounters* cc, RenderCounters* rc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t n = cc->n_hits[bounce];
+    const int n_lights = S.n_lights;
+    unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
+    for (;;) {
+        const uint32_t base = grab_batch(&cc->work_shade[bounce]);
+        if (base >= n) break;
+        const uint32_t j = base + lane_id();
+        const bool active = j < n;
+        Ray r{0, 0, 0, 0, 0, 0};
+        double w = 0.0, t = 0.0; uint32_t slot = 0, id0 = 0, id1 = 0;
+        if (active) {
+            const uint32_t i = hit_list[j];
+            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
+            w = rays.w[i]; slot = rays.slot[i];
+            t = hits.t[i]; id0 = hits.id0[i]; id1 = hits.id1[i];
+        }
+        // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
+        const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
+        Surface sf{{0, 0, 0}, {0, 1, 0}, 0};
+        if (active) sf = surface_at(S, ro, t, id0, id1);
+        const Material mat = S.materials[sf.material];             // per-lane gather (64 B records, L1/L2 resident)
+        const bool lit = active && mat.apply_lighting != 0;
+        double cr = 0.0, cg = 0.0, cb = 0.0;                       // sum over fragments (Seq.sumBy shader, Shading.fs:139)
+        // getLightsOnPoint (Shading.fs:109-117)
+        const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
+        for (int l = 0; l < n_lights; ++l) {                       // wave-uniform
+            const Light& lt = S.lights[l];
+            if (active && !lit) { cr += mat.colour[0]; cg += mat.colour[1]; cb += mat.colour[2]; }   // shadeIfRequired (Shading.fs:100-104)
+            Query<true> q;
+            q.active = lit; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0;
+            Ray sr; double intensity = 1.0; V3 ld;
+            if (lt.kind == LT_POINT) {                             // shadowLightIntensity / lightDirection (Shading.fs:33-48)
+                const double ddx = lt.v[0] - sox, ddy = lt.v[1] - soy, ddz = lt.v[2] - soz;
+                const double dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+                const V3 dn = normalise(V3{ddx, ddy, ddz});
+                sr = {sox, soy, soz, dn.x, dn.y, dn.z};
+                q.max_dist = dist;
+                intensity = 1.0 / (lt.falloff[0] + dist * (lt.falloff[1] + dist * lt.falloff[2]));   // Light.attenuate (Light.fs:16-17)
+                ld = normalise(V3{sf.p.x - lt.v[0], sf.p.y - lt.v[1], sf.p.z - lt.v[2]});
+            } else {
+                sr = {sox, soy, soz, -lt.v[0], -lt.v[1], -lt.v[2]};
+                q.max_dist = 1.7976931348623157e308;               // System.Double.MaxValue
+                ld = {lt.v[0], lt.v[1], lt.v[2]};
+            }
+            bool overflow = false;
+            if (__any(lit)) trace<true>(S, sr, q, lds, overflow);
+            n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
+            n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && lit));
+            if (lit) {
+                if (q.blocked) intensity = 0.0;
+                const double lcr = intensity * lt.colour[0], lcg = intensity * lt.colour[1], lcb = intensity * lt.colour[2];   // scaleColour (Image.fs:25-26)
+                // specularShader (Shading.fs:78-87)
+                double fr = 0.0, fg = 0.0, fb = 0.0;
+                {
+                    const V3 nn = normalise(sf.n);
+                    const double k2 = 2.0 * dot3(ld.x, ld.y, ld.z, nn.x, nn.y, nn.z);
+                    const V3 rl = normalise(V3{ld.x - k2 * nn.x, ld.y - k2 * nn.y, ld.z - k2 * nn.z});         // Vector.reflect (CommonTypes.fs:72)
+                    const V3 vd = normalise(V3{r.dx, r.dy, r.dz});
+                    const double si = pow(dot3(vd.x, vd.y, vd.z, -rl.x, -rl.y, -rl.z), mat.shineyness);
+                    if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
+                }
+                // reflectionShader is carried by the path weight (below); lambertianDiffuse (Shading.fs:65-70)
+                {
+                    const double di = dot3(-ld.x, -ld.y, -ld.z, sf.n.x, sf.n.y, sf.n.z);
+                    fr = fr + di * (mat.colour[0] * lcr); fg = fg + di * (mat.colour[1] * lcg); fb = fb + di * (mat.colour[2] * lcb);
+                }
+                cr += fr; cg += fg; cb += fb;
+            }
+        }
+        if (active) {                                              // one ray per sample per bounce: no write conflicts, fixed order
+            acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
+        }
+        // reflectionShader (Shading.fs:89-98): every one of the L fragments adds reflectance * colour(reflected ray);
+        // with deterministic lights those L sub-traces are identical, so one ray carries weight L * reflectance.
+        const bool spawn = lit && mat.reflectance > 0.0 && bounce < max_depth;
+        const unsigned long long m = __ballot(spawn);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        uint32_t dst = 0;
+        if (lane_id() == 0 && cnt) dst = atomicAdd(&cc->n_rays[bounce + 1], cnt);
+        dst = __builtin_amdgcn_readfirstlane(dst);
+        if (spawn) {
+            const uint32_t o = dst + lanes_below(m);
+            const double k2 = 2.0 * dot3(r.dx, r.dy, r.dz, sf.n.x, sf.n.y, sf.n.z);
+            next.ox[o] = sf.p.x; next.oy[o] = sf.p.y; next.oz[o] = sf.p.z;
+            next.dx[o] = r.dx - k2 * sf.n.x; next.dy[o] = r.dy - k2 * sf.n.y; next.dz[o] = r.dz - k2 * sf.n.z;
+            next.w[o] = w * (mat.reflectance * (double)n_lights);
+            next.slot[o] = slot;
+        }
+        n_refl_wave += cnt;
+        n_hit_wave += (unsigned long long)__popcll(__ballot(active));
+    }
+    wave_add(&rc->rays_shadow, n_shadow_wave);
+    wave_add(&rc->rays_reflect, n_refl_wave);
+    wave_add(&rc->csg_overflow, n_ovf_wave);
+    // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts L shadow rays
+    // and each reflective hit L reflection rays (Shading.fs:109-139).
+    if (lane_id() == 0 && (n_hit_wave || n_refl_wave)) {
+        const double mult = pow((double)n_lights, (double)bounce);
+        atomicAdd(&rc->ref_equiv, mult * (double)n_lights * ((double)n_hit_wave + (double)n_refl_wave));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, double* __restrict__ out) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
+        double r = 0.0, g = 0.0, b = 0.0;                          // Array.average: sum from Zero in sample order, then DivideByInt
+        for (int s = 0; s < spp; ++s) {
+            const size_t i = (size_t)s * n_pix + p;
+            r += acc[i]; g += acc[(size_t)acc_stride + i]; b += acc[2 * (size_t)acc_stride + i];
+        }
+        out[3 * (size_t)p] = r / (double)spp; out[3 * (size_t)p + 1] = g / (double)spp; out[3 * (size_t)p + 2] = b / (double)spp;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene S, const double* __restrict__ o, const double* __restrict__ d, uint32_t n,
+                                                           int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t n_batches = (n + 63) / 64;
+    for (uint32_t b = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; b < n_batches; b += gridDim.x * (kBlock / 64)) {
+        const uint32_t i = b * 64 + lane_id();
+        Query<false> q;
+        q.active = i < n; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0; q.blocked = false;
+        Ray r{0, 0, 0, 0, 0, 0};
+        if (q.active) r = {o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+        bool overflow;
+        trace<false>(S, r, q, lds, overflow);
+        if (q.active) {
+            const bool h = q.id0 != ID_MISS;
+            hit[i] = h ? 1 : 0;
+            Surface sf{{0, 0, 0}, {1, 0, 0}, 0};
+            double col[3] = {1, 1, 1};
+            if (h) { sf = surface_at(S, r, q.best_t, q.id0, q.id1); const Material m = S.materials[sf.material]; col[0] = m.colour[0]; col[1] = m.colour[1]; col[2] = m.colour[2]; }
+            t[i] = h ? q.best_t : 0.0;
+            p[3 * i] = sf.p.x; p[3 * i + 1] = sf.p.y; p[3 * i + 2] = sf.p.z;
+            nrm[3 * i] = sf.n.x; nrm[3 * i + 1] = sf.n.y; nrm[3 * i + 2] = sf.n.z;
+            colour[3 * i] = col[0]; colour[3 * i + 1] = col[1]; colour[3 * i + 2] = col[2];
+            if (overflow) atomicAdd(&rc->csg_overflow, 1ull);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene S, const double* __restrict__ o, const double* __restrict__ d,
+                                                           const double* __restrict__ max_dist, uint32_t n, int32_t* blocked, RenderCounters* rc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t n_batches = (n + 63) / 64;
+    for (uint32_t b = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; b < n_batches; b += gridDim.x * (kBlock / 64)) {
+        const uint32_t i = b * 64 + lane_id();
+        Query<true> q;
+        q.active = i < n; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0; q.max_dist = 0;
+        Ray r{0, 0, 0, 0, 0, 0};
+        if (q.active) { r = {o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]}; q.max_dist = max_dist[i]; }
+        bool overflow;
+        trace<true>(S, r, q, lds, overflow);
+        if (q.active) { blocked[i] = q.blocked ? 1 : 0; if (overflow) atomicAdd(&rc->csg_overflow, 1ull); }
+    }
+}
+
+} // namespace
+
+// ============================================================================================ launchers
+static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
+
+void launch_generate(const Launch& L, const Camera& cam, const uint32_t* pixel_ids, uint32_t pix_base, uint32_t n_pix, int32_t spp,
+                     const double* jitter, RayBuf rays, double* acc, ChunkCounters* cc) {
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_pix * (uint32_t)spp, L.grid * 4)), dim3(kBlock), 0, L.stream, cam, pixel_ids, pix_base, n_pix, spp, jitter, rays, acc, cc);
+}
+void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, ChunkCounters* cc, RenderCounters* rc) {
+    hipLaunchKernelGGL(k_closest, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, rays, hits, hit_list, bounce, cc, rc);
+}
+void launch_shade(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
+                  uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
+    hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
+}
+void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, double* out_rgb) {
+    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, n_pix, spp, out_rgb);
+}
+void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n, int32_t* hit, double* t,
+                          double* p, double* nrm, double* colour, RenderCounters* rc) {
+    hipLaunchKernelGGL(k_debug_closest, dim3(blocks_for(n, L.grid)), dim3(kBlock), L.lds_bytes, L.stream, S, o, d, n, hit, t, p, nrm, colour, rc);
+}
+void launch_debug_blocked(const Launch& L, const DevScene& S, const double* o, const double* d, const double* max_dist, uint32_t n,
+                          int32_t* blocked, RenderCounters* rc) {
+    hipLaunchKernelGGL(k_debug_blocked, dim3(blocks_for(n, L.grid)), dim3(kBlock), L.lds_bytes, L.stream, S, o, d, max_dist, n, blocked, rc);
+}
+
+} // namespace ftk
+
+// Resident workgroups per CU for the persistent grids (register- and LDS-limited).
+namespace ftk {
+static int clamp_blocks(int n) { return n < 1 ? 1 : (n > 8 ? 8 : n); }
+int occupancy_blocks_closest(size_t lds_bytes) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest, kBlock, lds_bytes) != hipSuccess) n = 2;
+    return clamp_blocks(n);
+}
+int occupancy_blocks_shade(size_t lds_bytes) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, lds_bytes) != hipSuccess) n = 2;
+    return clamp_blocks(n);
+}
+} // namespace ftk

@@ -1,0 +1,381 @@
+// ft_scene.cpp — scene-graph flattening and host-side BSP build for the HIP path.
+// Reference citations are relative to /root/reference/FuncTracer/.
+#include "ft_scene.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+
+namespace fth {
+namespace {
+
+// ------------------------------------------------------------------ 4x4 matrices (Transform.fs:7-22, 47-71)
+struct Mat4 { double a[16]; };
+
+Mat4 mat_identity() { Mat4 m{}; for (int i = 0; i < 4; ++i) m.a[5 * i] = 1.0; return m; }
+
+// Same accumulation order as Matrix (*) (Transform.fs:11-14): sum from 0 over c = 0..3.
+Mat4 mat_mul(const Mat4& l, const Mat4& r) {
+    Mat4 o{};
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) {
+            double s = 0.0;
+            for (int c = 0; c < 4; ++c) s = s + l.a[4 * row + c] * r.a[4 * c + col];
+            o.a[4 * row + col] = s;
+        }
+    return o;
+}
+
+double vec_len(const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+// matrix (Transform.fs:55-69) for one basic transform; `inverse` (Transform.fs:47-50) is applied by the caller.
+Mat4 basic_matrix(int kind, const double v[3], double angle) {
+    Mat4 m = mat_identity();
+    if (kind == FT_TRANSLATE) {
+        m.a[3] = v[0]; m.a[7] = v[1]; m.a[11] = v[2];
+    } else if (kind == FT_SCALE) {
+        m.a[0] = v[0]; m.a[5] = v[1]; m.a[10] = v[2];
+    } else {
+        const double ux = v[0], uy = v[1], uz = v[2];
+        const double c = std::cos(angle), invc = 1.0 - c, s = std::sin(angle);
+        m.a[0] = c + invc * ux * ux;      m.a[1] = invc * ux * uy - s * uz; m.a[2] = invc * ux * uz + s * uy;
+        m.a[4] = invc * ux * uy + s * uz; m.a[5] = c + invc * uy * uy;      m.a[6] = invc * uy * uz - s * ux;
+        m.a[8] = invc * ux * uz - s * uy; m.a[9] = invc * uy * uz + s * ux; m.a[10] = c + invc * uz * uz;
+    }
+    return m;
+}
+
+struct BasicXf { int kind; double v[3]; double angle; };
+
+BasicXf canonical(const ft_transform& t) {
+    BasicXf b{t.kind, {t.v[0], t.v[1], t.v[2]}, t.angle};
+    if (t.kind == FT_ROTATE) {                       // Transform.rotate normalises the axis (Transform.fs:37-38, CommonTypes.fs:63-67)
+        double l = vec_len(b.v);
+        if (!(l < 0.0000001)) { double s = 1.0 / l; b.v[0] = s * b.v[0]; b.v[1] = s * b.v[1]; b.v[2] = s * b.v[2]; }
+    }
+    return b;
+}
+BasicXf inverse_of(const BasicXf& b) {               // Transform.fs:47-50
+    BasicXf r = b;
+    if (b.kind == FT_TRANSLATE) { r.v[0] = -b.v[0]; r.v[1] = -b.v[1]; r.v[2] = -b.v[2]; }
+    else if (b.kind == FT_SCALE) { r.v[0] = 1.0 / b.v[0]; r.v[1] = 1.0 / b.v[1]; r.v[2] = 1.0 / b.v[2]; }
+    else r.angle = -b.angle;
+    return r;
+}
+// matrix of a (possibly Composed) transform level and of its inverse (Transform.fs:51, 70-71):
+// Composed [t1..tn] = M_n * (... * (M_1 * I)); inverse = Composed (rev (map inverse)).
+void level_matrices(const std::vector<ft_transform>& ts, Mat4& m2w, Mat4& w2m) {
+    std::vector<BasicXf> bs;
+    for (auto& t : ts) bs.push_back(canonical(t));
+    if (bs.size() == 1) {
+        m2w = basic_matrix(bs[0].kind, bs[0].v, bs[0].angle);
+        BasicXf inv = inverse_of(bs[0]);
+        w2m = basic_matrix(inv.kind, inv.v, inv.angle);
+        return;
+    }
+    m2w = mat_identity();
+    for (size_t i = 0; i < bs.size(); ++i) m2w = mat_mul(basic_matrix(bs[i].kind, bs[i].v, bs[i].angle), m2w);
+    w2m = mat_identity();
+    for (size_t i = bs.size(); i-- > 0;) { BasicXf inv = inverse_of(bs[i]); w2m = mat_mul(basic_matrix(inv.kind, inv.v, inv.angle), w2m); }
+}
+
+// ------------------------------------------------------------------ flatten
+struct MatFn { int kind; const GraphNode* node; };   // GraphNode::MaterialF / HueShift / IgnoreLight / Texture
+
+struct WalkCtx {
+    Mat4 m2w = mat_identity(), w2m = mat_identity();
+    bool xform = false;
+    std::vector<MatFn> fns;                          // outermost first
+};
+
+struct Flattener {
+    const SceneGraph& g;
+    FlatScene& out;
+    std::string& err;
+    std::map<int32_t, uint32_t> mesh_of_node;
+    int32_t status = FT_OK;
+    int csg_depth = 0, max_csg_depth = 0;
+    int cur_list = 0, max_list = 0;                  // static bound on the per-lane hit-list length
+
+    Flattener(const SceneGraph& g_, FlatScene& o, std::string& e) : g(g_), out(o), err(e) {}
+
+    uint32_t resolve_material(const WalkCtx& c) {
+        // Apply the enclosing scene functions innermost first; the outermost Material wins and resets
+        // applyLighting because it replaces the whole record (Ray.fs:47-59, SceneParser.fs:100-105).
+        ftd::Material m{};
+        m.colour[0] = m.colour[1] = m.colour[2] = 1.0;                       // Ray.mattWhite, Ray.fs:11
+        m.apply_lighting = 1; m.texture = -1; m.hue_rot = 0;
+        for (size_t i = c.fns.size(); i-- > 0;) {
+            const MatFn& f = c.fns[i];
+            if (f.kind == GraphNode::MaterialF) {
+                const ft_material& s = f.node->mat;
+                m.colour[0] = s.colour[0]; m.colour[1] = s.colour[1]; m.colour[2] = s.colour[2];
+                m.roughness = s.roughness; m.reflectance = s.reflectance; m.shineyness = s.shineyness;
+                m.apply_lighting = s.apply_lighting ? 1u : 0u; m.texture = -1; m.hue_rot = 0;
+            } else if (f.kind == GraphNode::IgnoreLight) {
+                m.apply_lighting = 0;
+            } else if (f.kind == GraphNode::HueShift) {                       // Colour.hueShift: (r,g,b) -> (b,r,g), CommonTypes.fs:90
+                if (m.texture >= 0) m.hue_rot = (m.hue_rot + 1) % 3;
+                else { double r = m.colour[0], gg = m.colour[1], b = m.colour[2]; m.colour[0] = b; m.colour[1] = r; m.colour[2] = gg; }
+            } else if (f.kind == GraphNode::Texture) {
+                out.any_texture = true;
+                m.texture = 0;
+            }
+        }
+        if (m.reflectance > 0.0 && m.apply_lighting) out.any_reflective = true;
+        for (size_t i = 0; i < out.materials.size(); ++i)
+            if (std::memcmp(&out.materials[i], &m, sizeof m) == 0) return (uint32_t)i;
+        out.materials.push_back(m);
+        return (uint32_t)out.materials.size() - 1;
+    }
+
+    void emit_leaf(uint32_t kind, uint32_t mesh, const WalkCtx& c, bool flip, bool in_csg, int max_hits) {
+        ftd::Leaf L{};
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) L.w2m[4 * r + k] = c.w2m.a[4 * r + k];
+        L.kind = kind; L.mesh = mesh;
+        L.material = resolve_material(c);
+        L.flags = (flip ? ftd::LF_FLIP : 0u) | (c.xform ? ftd::LF_XFORM : 0u) | (out.materials[L.material].apply_lighting ? ftd::LF_LIT : 0u);
+        uint32_t id = (uint32_t)out.leaves.size();
+        out.leaves.push_back(L);
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) out.m2w.push_back(c.m2w.a[4 * r + k]);
+        out.program.push_back(ftd::make_op(in_csg ? ftd::OP_LEAF_PUSH : ftd::OP_LEAF_FOLD, id));
+        if (in_csg) { cur_list += max_hits; if (cur_list > max_list) max_list = cur_list; }
+    }
+
+    uint32_t mesh_for(int32_t node_id, const double* tris, int64_t n, int32_t depth) {
+        if (node_id >= 0) { auto it = mesh_of_node.find(node_id); if (it != mesh_of_node.end()) return it->second; }
+        ftd::Mesh m{};
+        int32_t rc = build_bsp(tris, n, depth, out, m, err);
+        if (rc != FT_OK) { status = rc; return 0; }
+        out.meshes.push_back(m);
+        uint32_t idx = (uint32_t)out.meshes.size() - 1;
+        if (node_id >= 0) mesh_of_node[node_id] = idx;
+        if ((int32_t)m.max_depth + 1 > out.stack_capacity && m.root >= 0) out.stack_capacity = (int32_t)m.max_depth + 1;
+        return idx;
+    }
+
+    void walk(int32_t id, const WalkCtx& c, bool in_csg) {
+        if (status != FT_OK) return;
+        const GraphNode& n = g.nodes[id];
+        switch (n.kind) {
+            case GraphNode::Prim: {
+                static const uint32_t kind_of[8] = {ftd::LK_CIRCLE, ftd::LK_SQUARE, ftd::LK_CUBE, ftd::LK_SPHERE, ftd::LK_PLANE, ftd::LK_CONE, ftd::LK_SOLIDCYL, ftd::LK_CYLINDER};
+                static const int max_hits[8] = {1, 1, 6, 2, 1, 2, 4, 2};
+                emit_leaf(kind_of[n.prim], 0, c, false, in_csg, max_hits[n.prim]);
+                break;
+            }
+            case GraphNode::TriangleP: {
+                uint32_t mesh = mesh_for(-1, n.tri, 1, 0);
+                if (status == FT_OK) emit_leaf(ftd::LK_MESH, mesh, c, false, in_csg, 1);
+                break;
+            }
+            case GraphNode::Mesh: {
+                uint32_t mesh = mesh_for(id, n.tris.data(), (int64_t)(n.tris.size() / 9), n.depth);
+                if (status == FT_OK) {
+                    if (in_csg) out.mesh_under_csg = true;
+                    emit_leaf(ftd::LK_MESH, mesh, c, false, in_csg, g.csg_mesh_capacity);
+                }
+                break;
+            }
+            case GraphNode::Transform: {
+                Mat4 m, w;
+                level_matrices(n.xf, m, w);
+                WalkCtx c2 = c;
+                c2.m2w = mat_mul(c.m2w, m);          // outer levels act last on points: M_outer * M_inner
+                c2.w2m = mat_mul(w, c.w2m);          // and first on rays:              W_inner * W_outer
+                c2.xform = true;
+                walk(n.children[0], c2, in_csg);
+                break;
+            }
+            case GraphNode::MaterialF: case GraphNode::HueShift: case GraphNode::IgnoreLight: case GraphNode::Texture: {
+                WalkCtx c2 = c;
+                c2.fns.push_back({(int)n.kind, &n});
+                walk(n.children[0], c2, in_csg);
+                break;
+            }
+            case GraphNode::Group: {
+                // Runs of bare Triangle primitives (the `mesh` keyword, SceneParser.fs:116-126) become one
+                // brute-force triangle list: identical hit sequence, one leaf instead of thousands.
+                size_t i = 0;
+                while (i < n.children.size() && status == FT_OK) {
+                    const GraphNode& ch = g.nodes[n.children[i]];
+                    if (ch.kind == GraphNode::TriangleP) {
+                        std::vector<double> run;
+                        while (i < n.children.size() && g.nodes[n.children[i]].kind == GraphNode::TriangleP) {
+                            const double* t = g.nodes[n.children[i]].tri; run.insert(run.end(), t, t + 9); ++i;
+                        }
+                        uint32_t mesh = mesh_for(-1, run.data(), (int64_t)(run.size() / 9), 0);
+                        if (status == FT_OK) emit_leaf(ftd::LK_MESH, mesh, c, false, in_csg, (int)std::min<size_t>(run.size() / 9, (size_t)g.csg_mesh_capacity));
+                    } else {
+                        walk(n.children[i], c, in_csg); ++i;
+                    }
+                }
+                break;
+            }
+            case GraphNode::Csg: {
+                ++csg_depth; if (csg_depth > max_csg_depth) max_csg_depth = csg_depth;
+                int before = cur_list;
+                out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
+                walk(n.children[0], c, true);
+                out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
+                walk(n.children[1], c, true);
+                out.program.push_back(ftd::make_op(ftd::OP_CSG, (uint32_t)n.op));
+                --csg_depth;
+                if (!in_csg) { out.program.push_back(ftd::make_op(ftd::OP_FOLD_LIST, 0)); cur_list = before; }
+                break;
+            }
+        }
+    }
+};
+
+} // namespace
+
+int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
+    out = FlatScene();
+    if (!valid(root)) { err = "scene has no objects (ft_scene_set_objects)"; return FT_ERR_STATE; }
+    Flattener f(*this, out, err);
+    WalkCtx c;
+    f.walk(root, c, false);
+    if (f.status != FT_OK) return f.status;
+    out.program.push_back(ftd::make_op(ftd::OP_END, 0));
+    out.lights = lights;
+    out.csg_capacity = f.max_list;
+    if (f.max_csg_depth > 8) { err = "CSG nesting deeper than 8 levels is not supported on the device path"; return FT_ERR_UNSUPPORTED; }
+    if (out.csg_capacity > 255) { err = "a CSG subtree can produce more than 255 hits per ray; lower csg_mesh_capacity"; return FT_ERR_UNSUPPORTED; }
+    if (out.leaves.size() > ftd::ID_LEAF_MASK) { err = "too many primitive instances"; return FT_ERR_UNSUPPORTED; }
+    if (out.any_texture) { err = "textures (Scene.fs:44) are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
+    for (auto& m : out.materials) if (m.roughness != 0.0) { err = "roughness != 0 (Oren-Nayar, Shading.fs:50-63) is not on the device path yet"; return FT_ERR_UNSUPPORTED; }
+    for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) { err = "softdirectional lights are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
+    if (out.tris.empty()) out.tris.assign(9, 0.0);   // keep device pointers non-null
+    return FT_OK;
+}
+
+// ====================================================================== BSP build (host)
+namespace {
+
+struct P3 { double x, y, z; };
+struct Tri3 { P3 a, b, c; };
+struct SplitPlane { P3 p0, n; };
+
+inline double dot3(P3 a, P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline P3 diff(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+inline bool above_plane(const SplitPlane& pl, P3 q) { return dot3(diff(q, pl.p0), pl.n) >= 0.0; }   // Plane.isAbove, Plane.fs:22-23
+
+// Triangle.edgeIntersection (Triangle.fs:8-10): Plane.intersect (Plane.fs:9-20) along the normalised edge.
+bool edge_cut(const SplitPlane& pl, P3 from, P3 to, P3& out) {
+    P3 d = diff(to, from);
+    double len = std::sqrt(dot3(d, d));
+    if (!(len < 0.0000001)) { double s = 1.0 / len; d = {s * d.x, s * d.y, s * d.z}; }                // CommonTypes.fs:63-67
+    const double eps = 0.0000001;
+    double num = dot3(diff(pl.p0, from), pl.n);
+    double den = dot3(d, pl.n);
+    if (std::fabs(den) < eps) { if (num < eps) { out = from; return true; } return false; }
+    double t = num / den;
+    out = {from.x + t * d.x, from.y + t * d.y, from.z + t * d.z};
+    return true;
+}
+
+// Triangle.slice' (Triangle.fs:13-22): `lone` is alone on its side; outputs one piece on the lone side
+// and two on the other, winding preserved.
+bool cut_lone(const SplitPlane& pl, P3 lone, P3 q, P3 r, std::vector<Tri3>& lone_side, std::vector<Tri3>& pair_side) {
+    P3 lq, lr, ql, rl;
+    if (!edge_cut(pl, lone, q, lq) || !edge_cut(pl, lone, r, lr) || !edge_cut(pl, q, lone, ql) || !edge_cut(pl, r, lone, rl)) return false;
+    lone_side.push_back({lone, lq, lr});
+    pair_side.push_back({ql, q, r});
+    pair_side.push_back({r, rl, ql});
+    return true;
+}
+
+// Triangle.slice (Triangle.fs:24-41).
+bool split_triangle(const SplitPlane& pl, const Tri3& t, std::vector<Tri3>& above, std::vector<Tri3>& below) {
+    const bool ua = above_plane(pl, t.a), ub = above_plane(pl, t.b), uc = above_plane(pl, t.c);
+    if (ua == ub && ub == uc) { (ua ? above : below).push_back(t); return true; }
+    if (ua == ub) return cut_lone(pl, t.c, t.a, t.b, uc ? above : below, uc ? below : above);   // c is alone
+    if (ua == uc) return cut_lone(pl, t.b, t.c, t.a, ub ? above : below, ub ? below : above);   // b is alone
+    return cut_lone(pl, t.a, t.b, t.c, ua ? above : below, ua ? below : above);                 // a is alone
+}
+
+struct BspBuilder {
+    FlatScene& out;
+    std::string& err;
+    uint32_t max_depth = 0;
+    bool failed = false;
+
+    int32_t make_leaf(const std::vector<Tri3>& ts) {
+        ftd::BspLeaf L{(uint32_t)(out.tris.size() / 9), (uint32_t)ts.size()};
+        for (auto& t : ts) {                                                    // v0, edge1, edge2 (Triangle.fs:45-46)
+            const double rec[9] = {t.a.x, t.a.y, t.a.z, t.b.x - t.a.x, t.b.y - t.a.y, t.b.z - t.a.z, t.c.x - t.a.x, t.c.y - t.a.y, t.c.z - t.a.z};
+            out.tris.insert(out.tris.end(), rec, rec + 9);
+        }
+        out.bsp_leaves.push_back(L);
+        return ~(int32_t)(out.bsp_leaves.size() - 1);
+    }
+
+    // BspMesh.compile (BspMesh.fs:51-65); returns a child reference.
+    int32_t compile(int depth_left, const std::vector<Tri3>& ts, uint32_t level) {
+        if (failed) return -1;
+        if (depth_left == 0) return make_leaf(ts);
+        const double inf = std::numeric_limits<double>::infinity();            // BoundingBox.pointsBoundry, BoundingBox.fs:9-22
+        P3 lo{inf, inf, inf}, hi{-inf, -inf, -inf};
+        auto grow = [&](P3 q) {
+            if (q.x < lo.x) lo.x = q.x; if (q.y < lo.y) lo.y = q.y; if (q.z < lo.z) lo.z = q.z;
+            if (q.x > hi.x) hi.x = q.x; if (q.y > hi.y) hi.y = q.y; if (q.z > hi.z) hi.z = q.z;
+        };
+        for (auto& t : ts) { grow(t.a); grow(t.b); grow(t.c); }
+        const double wx = std::fabs(hi.x - lo.x) / 2.0, wy = std::fabs(hi.y - lo.y) / 2.0, wz = std::fabs(hi.z - lo.z) / 2.0;  // optimalSplit, BspMesh.fs:30-41
+        SplitPlane pl;
+        if (wx > wy && wx > wz) pl = {{(lo.x + hi.x) / 2.0, 0.0, 0.0}, {1.0, 0.0, 0.0}};
+        else if (wy > wz) pl = {{0.0, (lo.y + hi.y) / 2.0, 0.0}, {0.0, 1.0, 0.0}};
+        else pl = {{0.0, 0.0, (lo.z + hi.z) / 2.0}, {0.0, 0.0, 1.0}};
+        std::vector<Tri3> left, right;                                          // left = above pieces, right = below (BspMesh.fs:42-46)
+        for (auto& t : ts)
+            if (!split_triangle(pl, t, left, right)) {
+                failed = true;
+                err = "BSP build: a triangle edge parallel to the split plane has no intersection (Triangle.fs:10 takes .Value of None)";
+                return -1;
+            }
+        if (left.size() >= ts.size() || right.size() >= ts.size()) return make_leaf(ts);   // BspMesh.fs:59-60
+        int32_t idx = (int32_t)out.nodes.size();
+        out.nodes.push_back(ftd::BspNode{});
+        if (level + 1 > max_depth) max_depth = level + 1;
+        int32_t l = compile(depth_left - 1, left, level + 1);
+        int32_t r = compile(depth_left - 1, right, level + 1);
+        ftd::BspNode& nd = out.nodes[(size_t)idx];
+        nd.bmin[0] = lo.x; nd.bmin[1] = lo.y; nd.bmin[2] = lo.z; nd.bmax[0] = hi.x; nd.bmax[1] = hi.y; nd.bmax[2] = hi.z;
+        nd.left = l; nd.right = r;
+        return idx;
+    }
+};
+
+} // namespace
+
+int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatScene& out, ftd::Mesh& mesh, std::string& err) {
+    if (n_tris < 0 || (n_tris > 0 && !tris_abc) || depth < 0) { err = "bad mesh arguments"; return FT_ERR_INVALID; }
+    std::vector<Tri3> ts((size_t)n_tris);
+    for (int64_t i = 0; i < n_tris; ++i) {
+        const double* v = tris_abc + 9 * i;
+        ts[(size_t)i] = {{v[0], v[1], v[2]}, {v[3], v[4], v[5]}, {v[6], v[7], v[8]}};
+    }
+    BspBuilder b{out, err};
+    int32_t root = (n_tris == 0) ? b.make_leaf(ts) : b.compile(depth, ts, 0);   // an empty mesh is an empty group
+    if (b.failed) return FT_ERR_BUILD;
+    mesh.root = root; mesh.n_source_tris = (uint32_t)n_tris; mesh.max_depth = b.max_depth;
+    return FT_OK;
+}
+
+int32_t slice_triangle(const double p0[3], const double n[3], const double tri[9], std::vector<double>& above, std::vector<double>& below, std::string& err) {
+    SplitPlane pl{{p0[0], p0[1], p0[2]}, {n[0], n[1], n[2]}};
+    Tri3 t{{tri[0], tri[1], tri[2]}, {tri[3], tri[4], tri[5]}, {tri[6], tri[7], tri[8]}};
+    std::vector<Tri3> a, b;
+    if (!split_triangle(pl, t, a, b)) { err = "edge parallel to plane"; return FT_ERR_BUILD; }
+    auto dump = [](const std::vector<Tri3>& v, std::vector<double>& o) {
+        o.clear();
+        for (auto& q : v) { const double w[9] = {q.a.x, q.a.y, q.a.z, q.b.x, q.b.y, q.b.z, q.c.x, q.c.y, q.c.z}; o.insert(o.end(), w, w + 9); }
+    };
+    dump(a, above); dump(b, below);
+    return FT_OK;
+}
+
+} // namespace fth

@@ -1,0 +1,65 @@
+// ft_scene.h — host-side scene graph arena (mirror of Scene.fs:8-53, 107-110) and its
+// compilation to the flat HBM layout of ft_flat.h.  Pure C++; no HIP here.
+#ifndef FT_SCENE_H
+#define FT_SCENE_H
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/functracer_hip.h"
+#include "ft_flat.h"
+
+namespace fth {
+
+struct GraphNode {
+    enum Kind { Prim, TriangleP, Mesh, Transform, MaterialF, HueShift, IgnoreLight, Texture, Group, Csg } kind = Prim;
+    int32_t prim = 0;                 // ft_primitive_kind
+    double tri[9] = {0};              // TriangleP
+    int32_t depth = 0;                // Mesh: BspMesh.bspMesh depth
+    std::vector<double> tris;         // Mesh: n x 9 (a,b,c)
+    std::vector<ft_transform> xf;     // Transform: one basic transform or a Composed list
+    ft_material mat{};                // MaterialF
+    int32_t op = 0;                   // Csg
+    std::vector<int32_t> children;
+    double ca[3] = {0}, cb[3] = {0};  // Texture grid colours
+    std::vector<double> uv_ops;
+};
+
+struct FlatScene {
+    std::vector<ftd::Leaf> leaves;
+    std::vector<double> m2w;          // 12 per leaf
+    std::vector<ftd::Material> materials;
+    std::vector<ftd::Light> lights;
+    std::vector<uint32_t> program;
+    std::vector<ftd::Mesh> meshes;
+    std::vector<ftd::BspNode> nodes;
+    std::vector<ftd::BspLeaf> bsp_leaves;
+    std::vector<double> tris;         // 9 per triangle: v0, e1, e2
+    int32_t csg_capacity = 0;         // per-lane hit-list entries needed (0 = scene has no CSG)
+    int32_t stack_capacity = 0;       // per-lane BSP stack entries needed (0 = no BSP branches)
+    bool any_reflective = false;
+    bool any_texture = false;
+    bool mesh_under_csg = false;
+};
+
+struct SceneGraph {
+    std::vector<GraphNode> nodes;
+    int32_t root = -1;
+    std::vector<ftd::Light> lights;
+    int32_t csg_mesh_capacity = 32;
+
+    bool valid(int32_t id) const { return id >= 0 && id < (int32_t)nodes.size(); }
+    // Returns FT_OK or a negative ft_status with err set.
+    int32_t flatten(FlatScene& out, std::string& err) const;
+};
+
+// BspMesh.compile (BspMesh.fs:51-65) on the host: appends nodes / leaves / clipped triangles to
+// the flat arrays and returns the root reference (>= 0 branch node, < 0 ~leaf) via mesh.
+int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatScene& out, ftd::Mesh& mesh, std::string& err);
+
+// Triangle.slice (Triangle.fs:24-41) exposed for the known-answer tests of the product's own builder.
+int32_t slice_triangle(const double p0[3], const double n[3], const double tri[9],
+                       std::vector<double>& above, std::vector<double>& below, std::string& err);
+
+} // namespace fth
+#endif

@@ -1,0 +1,198 @@
+/*
+ * functracer_hip.h — C ABI of libfunctracer_hip.so, the MI355X (gfx950) replacement for
+ * FuncTracer's per-pixel render loop.
+ *
+ * The reference (antonburger/FuncTracer, F#) has no FFI seam of its own.  The seam this
+ * library fills is the module surface of Scene.fs + Image.fs as consumed by SceneParser.fs
+ * and Program.fs:
+ *
+ *   - the ft_sg_* / ft_scene_* builder mirrors the constructors of Scene.Primitive
+ *     (Scene.fs:8-18), Scene.SceneGraph / SceneFunction (Scene.fs:33-46), Transform
+ *     (Transform.fs:25-38), Ray.Material (Ray.fs:4-10), Light (Light.fs:19-26) and
+ *     Scene.Scene (Scene.fs:107-110);
+ *   - ft_render replaces, in one call, what Program.fs:54-64 does on the CPU:
+ *     ImagePlane.create (Image.fs:67-81), JitteredSampling.generateRays (Image.fs:100-110),
+ *     Shading.shade (Shading.fs:141-147) and JitteredSampling.blendPixels (Image.fs:112-116);
+ *   - ft_quantise_rgba8 is Image.write's toByte (Image.fs:36).
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Functions returning int32_t return
+ * FT_OK (0) or a negative ft_status; functions returning ft_node return a non-negative handle
+ * or a negative ft_status.  ft_last_error(ctx) gives a UTF-8 message owned by the context.
+ * All arrays are caller-owned and only read for the duration of the call.  A context is not
+ * re-entrant (one call at a time); different contexts may be used from different threads.
+ * All floating point is IEEE double, as in the reference (F# float).
+ *
+ * There is NO CPU fallback: ft_create fails with FT_ERR_NO_DEVICE when no HIP device is
+ * usable.  The CPU restatement under oracle/ is test infrastructure and is never linked here.
+ */
+#ifndef FUNCTRACER_HIP_H
+#define FUNCTRACER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FT_ABI_VERSION 1
+
+typedef struct ft_context ft_context;
+typedef int32_t ft_node;
+
+typedef enum ft_status {
+    FT_OK = 0,
+    FT_ERR_INVALID = -1,      /* bad argument / bad handle                                   */
+    FT_ERR_NO_DEVICE = -2,    /* no usable HIP device (there is no CPU fallback)            */
+    FT_ERR_HIP = -3,          /* a HIP runtime call failed; see ft_last_error               */
+    FT_ERR_UNSUPPORTED = -4,  /* part of the Scene.fs surface not on the device path yet     */
+    FT_ERR_STATE = -5,        /* call order violated (e.g. render before commit)            */
+    FT_ERR_OVERFLOW = -6,     /* a per-ray CSG hit list exceeded its capacity (never silent) */
+    FT_ERR_BUILD = -7         /* BSP build failed (degenerate edge, see Triangle.fs:8-10)    */
+} ft_status;
+
+/* Scene.Primitive without payload, in the order of Scene.fs:10-17. */
+typedef enum ft_primitive_kind {
+    FT_PRIM_CIRCLE = 0,         /* Cylinder.circle        Cylinder.fs:22    */
+    FT_PRIM_SQUARE = 1,         /* Cube.square            Cube.fs:9-15      */
+    FT_PRIM_CUBE = 2,           /* Cube.cube              Cube.fs:17-25     */
+    FT_PRIM_SPHERE = 3,         /* Sphere.sphere          Sphere.fs:11-21   */
+    FT_PRIM_PLANE = 4,          /* Plane.plane            Plane.fs:28-33    */
+    FT_PRIM_CONE = 5,           /* Cone.cone              Cone.fs:7-27      */
+    FT_PRIM_SOLID_CYLINDER = 6, /* Cylinder.solidCylinder Cylinder.fs:25-29 */
+    FT_PRIM_CYLINDER = 7        /* Cylinder.cylinder      Cylinder.fs:8-20  */
+} ft_primitive_kind;
+
+/* Csg.union / intersect / subtract / exclude, Csg.fs:96-99, Scene.fs:36-39. */
+typedef enum ft_csg_op { FT_CSG_UNION = 0, FT_CSG_INTERSECT = 1, FT_CSG_SUBTRACT = 2, FT_CSG_EXCLUDE = 3 } ft_csg_op;
+
+/* One basic Transform.Transform (Transform.fs:25-29).  A list of them is a Composed
+ * (Transform.fs:30, 41-45): first listed is applied first (Transform.fs:70-71). */
+typedef enum ft_transform_kind { FT_TRANSLATE = 0, FT_SCALE = 1, FT_ROTATE = 2 } ft_transform_kind;
+typedef struct ft_transform {
+    int32_t kind;     /* ft_transform_kind                                                   */
+    int32_t _pad;
+    double v[3];      /* translation vector | scale factors | rotation axis (normalised by the
+                         library exactly as Transform.rotate does, Transform.fs:37-38)       */
+    double angle;     /* radians, FT_ROTATE only                                             */
+} ft_transform;
+
+/* Ray.Material (Ray.fs:4-10). */
+typedef struct ft_material {
+    double colour[3];
+    double roughness;
+    double reflectance;
+    double shineyness;
+    int32_t apply_lighting; /* bool */
+    int32_t _pad;
+} ft_material;
+
+/* Image.Camera (Image.fs:10-17).  focus (depth of field, Image.fs:91-94) draws from an unseeded
+ * System.Random in the reference; has_focus != 0 is rejected with FT_ERR_UNSUPPORTED this round. */
+typedef struct ft_camera {
+    double o[3];
+    double look_at[3];
+    double up[3];
+    double fov_y;        /* radians */
+    double aspect_ratio;
+    int32_t has_focus;
+    int32_t _pad;
+    double focal_length;
+    double aperture_angular_size; /* radians */
+} ft_camera;
+
+typedef struct ft_rect { int32_t x0, y0, w, h; } ft_rect;
+
+/* Counters and timings of one ft_render call. */
+typedef struct ft_stats {
+    uint64_t rays_primary;   /* W*H*spp over the rendered tiles                                */
+    uint64_t rays_shadow;    /* shadow rays actually traced                                    */
+    uint64_t rays_reflect;   /* reflection rays actually traced                                */
+    uint64_t rays_traced;    /* sum of the three                                               */
+    double   rays_reference_equivalent; /* what the F# recursion would trace (Shading.fs:109-139):
+                                L shadow rays per hit and L reflection rays per reflective hit  */
+    uint64_t hits_primary;   /* primary rays that hit something                                */
+    uint64_t csg_overflow;   /* rays whose CSG hit list overflowed (render then fails)         */
+    double   kernel_ms;      /* HIP-event time over all kernels of the call, on the library's stream */
+    double   wall_ms;        /* host wall time of the call incl. copies                        */
+    double   trace_kernel_ms;/* HIP-event time of the closest-hit + shade/shadow kernels only  */
+    uint64_t algorithmic_bytes; /* sizeof(RayRec)*2+sizeof(HitRec)*2 per traced ray + 24 B/pixel */
+    int32_t  n_launches;
+    int32_t  n_chunks;
+} ft_stats;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int32_t ft_abi_version(void);
+/* device_ids: HIP device ordinals; n_devices must be >= 1 (0 ⇒ FT_ERR_NO_DEVICE: no CPU path). */
+int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out);
+void    ft_destroy(ft_context* ctx);
+const char* ft_last_error(const ft_context* ctx);
+/* Tunables: "chunk_samples" (samples in flight per launch), "csg_mesh_capacity". */
+int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
+
+/* ---- scene graph builder (Scene.fs:8-53) ------------------------------------------------- */
+ft_node ft_sg_primitive(ft_context* ctx, int32_t kind);                       /* Scene.fs:10-17  */
+ft_node ft_sg_triangle(ft_context* ctx, const double v[9]);                   /* Scene.fs:18     */
+/* BspMesh.bspMesh false depth triangles (BspMesh.fs:88-97); tris = n x 9 doubles (a,b,c). */
+ft_node ft_sg_bsp_mesh(ft_context* ctx, int32_t depth, const double* tris, int64_t n_tris); /* Scene.fs:9 */
+ft_node ft_sg_transform(ft_context* ctx, const ft_transform* ts, int32_t n, ft_node child); /* Scene.fs:42 */
+ft_node ft_sg_material(ft_context* ctx, const ft_material* m, ft_node child);  /* Scene.fs:43     */
+ft_node ft_sg_hue_shift(ft_context* ctx, double angle, ft_node child);         /* Scene.fs:45     */
+ft_node ft_sg_ignore_light(ft_context* ctx, ft_node child);                    /* Scene.fs:46     */
+ft_node ft_sg_group(ft_context* ctx, const ft_node* children, int32_t n);      /* Scene.fs:35     */
+ft_node ft_sg_csg(ft_context* ctx, int32_t op, ft_node a, ft_node b);          /* Scene.fs:36-39  */
+/* Scene.fs:44,47-53: Grid textures; Image textures are out of scope (need files/HTTP). */
+ft_node ft_sg_texture_grid(ft_context* ctx, const double colour_a[3], const double colour_b[3],
+                           const double* uv_ops, int32_t n_uv_ops, ft_node child);
+
+/* ---- scene (Scene.fs:107-110, Light.fs:19-26) -------------------------------------------- */
+int32_t ft_scene_clear(ft_context* ctx);
+int32_t ft_scene_set_objects(ft_context* ctx, ft_node root);
+int32_t ft_scene_add_directional(ft_context* ctx, const double dir[3], const double colour[3]);
+int32_t ft_scene_add_soft_directional(ft_context* ctx, const double dir[3], int32_t samples,
+                                      double scatter_rad, const double colour[3]);
+int32_t ft_scene_add_positional(ft_context* ctx, const double pos[3], const double falloff[3],
+                                const double colour[3]);
+/* Flatten the graph, build BSP trees (BspMesh.compile, BspMesh.fs:51-65) and upload to HBM. */
+int32_t ft_scene_commit(ft_context* ctx);
+
+/* ---- render (Program.fs:54-64) ----------------------------------------------------------- */
+/* res_h x res_v is Image.Resolution (Image.fs:28).  jitter_xy = spp x 2 offsets, the ONE pattern
+ * shared by every pixel (Image.fs:105).  max_depth = the recursion limit (8 in Shading.fs:142).
+ * seed keys the counter-based streams of soft lights.  tiles == NULL renders the whole frame;
+ * otherwise only pixels inside the n_tiles rects are written.  out_rgb is res_v x res_h x 3
+ * doubles, row 0 = top (Image.fs:39).  out_rgb may be NULL: the frame then stays in HBM until
+ * ft_fetch_frame copies it out (same layout; only the last render's tile pixels are written). */
+int32_t ft_render(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp,
+                  const double* jitter_xy, int32_t max_depth, uint64_t seed,
+                  const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats);
+
+int32_t ft_fetch_frame(ft_context* ctx, double* out_rgb);
+
+/* Closest hit of single rays through the device path (Scene.intersectScene, Scene.fs:118, after
+ * Shading.slightOffset is NOT applied): for tests.  Outputs per ray: t, p[3], n[3], material index
+ * resolved colour[3]; hit[i] = 0 when the ray misses. */
+int32_t ft_debug_closest(ft_context* ctx, const double* origins, const double* dirs, int64_t n,
+                         int32_t* hit, double* t, double* p, double* nrm, double* colour);
+/* lightIsBocked (Scene.fs:119-121) for single rays. */
+int32_t ft_debug_blocked(ft_context* ctx, const double* origins, const double* dirs,
+                         const double* max_dist, int64_t n, int32_t* blocked);
+
+/* Host-logic test hooks (no device work): a context that can build, flatten and BSP-compile a scene
+ * but whose render/debug calls fail with FT_ERR_NO_DEVICE; flattened-scene sizes
+ * (out = leaves, program words, meshes, bsp nodes, bsp leaves, triangles, csg capacity, stack capacity);
+ * and Triangle.slice (Triangle.fs:24-41) as the BSP builder implements it (9 doubles per triangle,
+ * at most 2 triangles per side). */
+int32_t ft_create_host_only(ft_context** out);
+int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[8]);
+int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9],
+                       double above[18], int32_t* n_above, double below[18], int32_t* n_below);
+/* HIP-event time per kernel over the last ft_render: index 0 generate, 1 closest, 2 shade, 3 blend. */
+int32_t ft_get_kernel_times(ft_context* ctx, double ms[4], int32_t launches[4]);
+
+/* Image.write's toByte (Image.fs:36): clamp to [0,1], *255, truncate; alpha = 255. */
+int32_t ft_quantise_rgba8(const double* rgb, int64_t n_pixels, uint8_t* out_rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

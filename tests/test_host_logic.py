@@ -1,0 +1,182 @@
+"""Host-side logic that needs no GPU: the .scene / PLY loaders, scene flattening and the product's
+own BSP builder (through the host-only test hook of the C ABI), and the exported ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import functracer_amd as ft
+from oracle import ft_oracle_py as O
+
+from . import helpers as H
+
+
+def test_colour_literals(golden):                             # FuncTracer.Tests/Parser/Colour.fs:17-30
+    for case in golden["reference_tests"]["colour"]["cases"]:
+        assert list(ft.parse_colour(case["text"])) == case["expect"]
+    with pytest.raises(ValueError):
+        ft.parse_colour("red")
+
+
+def test_scene_parser_options_and_counts():
+    p = ft.parse_scene_file(H.scene_path("night-house-det"))
+    assert p.resolution == (1920, 1080) and p.samples == 16 and not p.corner
+    assert p.n_objects == 5 and p.n_lights == 3
+    assert list(p.camera.o) == [15.0, 11.0, -20.0] and p.camera.fov_y == pytest.approx(np.pi / 3)
+    d = ft.parse_scene("(material diffuse 1 reflectance 0 shineyness 0 sphere)\n")        # defaults: Scene.fs:61-65
+    assert d.resolution == (400, 400) and d.samples == 8 and d.camera.fov_y == pytest.approx(50 * np.pi / 180)
+    assert ft.parse_scene("samples corner\nsphere\n").corner
+
+
+def test_scene_parser_errors_and_order():
+    with pytest.raises(ValueError):
+        ft.parse_scene("(material diffuse 1 spher)\n")
+    with pytest.raises(ValueError):                           # lights before objects: sections are ordered (SceneParser.fs:357)
+        ft.parse_scene("directional dir (0,-1,0) colour 1\nsphere\n")
+    with pytest.raises(ValueError):
+        ft.parse_scene('bspMesh 0 "does-not-exist.ply"\n')
+
+
+def test_repeat_yields_n_plus_one_copies():                   # SceneParser.fs:242-251
+    p = ft.parse_scene("(repeat 8 translate (-0.4,0,-1) (translate (-2,0,-5) sphere))\n")
+    ctx = ft.Context(host_only=True)
+    p.lower(ctx)
+    assert ctx.scene_info()["leaves"] == 9
+    orc = O.Oracle()
+    p.lower(orc)
+    # copy k (1-based) sits at (-2,0,-5) + k * (-0.4,0,-1); the untranslated original is not part of the group
+    for k in range(1, 10):
+        c = np.array([-2 - 0.4 * k, 0.0, -5 - 1.0 * k])
+        hit, t, *_ = orc.closest([c + [0, 5, 0]], [[0, -1, 0]])
+        assert hit[0] == 1 and t[0] == pytest.approx(4.0)
+    hit, *_ = orc.closest([[-2, 5, -5]], [[0, -1, 0]])
+    assert hit[0] == 0
+
+
+def test_composed_function_applies_first_listed_first():      # SceneParser.fs:235-239
+    p = ft.parse_scene("((translate (1,0,0)) . (scale (2,2,2) ) sphere )\n")
+    orc = O.Oracle()
+    p.lower(orc)
+    hit, t, pp, *_ = orc.closest([[2, 0, -9]], [[0, 0, 1]])  # scale(translate(sphere)): centre (2,0,0), radius 2
+    assert hit[0] == 1 and pp[0][2] == pytest.approx(-2.0)
+
+
+def test_ply_loader_layout():                                 # PlyParser.fs:20-61
+    text = "ply\nformat ascii 1.0\ncomment x\nelement vertex 3\nproperty float x\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n" \
+           "0 0 0 1 0.5\n1 0 0 1 0.5\n0 1 0 1 0.5\n3 0 1 2\n"
+    tris = ft.parse_ply(text)
+    assert tris.shape == (1, 9) and list(tris[0]) == [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    with pytest.raises(ValueError):                           # 3 numbers per vertex is not the accepted layout (pipe5, PlyParser.fs:42-49)
+        ft.parse_ply(text.replace(" 1 0.5", ""))
+    with pytest.raises(ValueError):
+        ft.parse_ply(text.replace("3 0 1 2", "4 0 1 2 0"))
+    full = open(H.scene_path("meshes/bunny_synth_res4").replace(".scene", ".ply")).read()
+    assert ft.parse_ply(full).shape == (980, 9)
+
+
+def test_product_slice_matches_reference_vectors(golden):     # Triangle.Tests.fs:12-54 against the product's BSP builder
+    g = golden["reference_tests"]["triangle_slice"]
+    a, b, c = g["a"], g["b"], g["c"]
+    ab, ac = g["ab_intercept"], g["ac_intercept"]
+    for tri in ([a, b, c], [c, a, b], [b, c, a]):
+        above, below = ft.debug_slice(g["plane_p0"], g["plane_n"], tri)
+        assert np.array_equal(above, np.array([[a, ab, ac]]))
+        assert np.array_equal(below, np.array([[ab, b, c], [c, ac, ab]]))
+    above, below = ft.debug_slice(g["plane_p0"], g["plane_n"], g["wholly_above"])
+    assert np.array_equal(above[0], np.array(g["wholly_above"])) and below.shape[0] == 0
+    above, below = ft.debug_slice(g["plane_p0"], g["plane_n"], g["wholly_below"])
+    assert np.array_equal(below[0], np.array(g["wholly_below"])) and above.shape[0] == 0
+
+
+def test_product_slice_matches_oracle_on_random_triangles():
+    rng = np.random.default_rng(4)
+    for _ in range(300):
+        tri = rng.normal(size=(3, 3))
+        p0, n = rng.normal(size=3) * 0.3, np.eye(3)[rng.integers(0, 3)]
+        ga, gb = ft.debug_slice(p0, n, tri)
+        wa, wb = O.slice_triangle(p0, n, tri)
+        assert np.array_equal(ga, wa) and np.array_equal(gb, wb)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 4, 12])
+def test_product_bsp_build_matches_oracle_statistics(depth):  # BspMesh.fs:51-65, 78-86: two independent builders agree
+    tris = ft.parse_ply(open(H.scene_path("meshes/bunny_synth_res4").replace(".scene", ".ply")).read())
+    ctx = ft.Context(host_only=True)
+    ctx.clear(); ctx.set_objects(ctx.group([ctx.bsp_mesh(depth, tris)])); ctx.commit()
+    info = ctx.scene_info()
+    st = O.bsp_stats(tris, depth)
+    assert info["bsp_leaves"] == st["leaves"] and info["triangles"] == st["leaf_triangles"]
+    assert info["bsp_nodes"] == st["leaves"] - 1
+    assert info["stack_capacity"] == (st["max_depth"] + 1 if st["max_depth"] else 0)
+
+
+def test_flatten_config_scenes():
+    ctx = ft.Context(host_only=True)
+    expect = {"hollow-sphere": (52, 8), "night-house-det": (2 + 1 + 9 + 4 + 3 + 1, 6), "bunny": (1, 0)}
+    for name, (leaves, csg_cap) in expect.items():
+        ft.parse_scene_file(H.scene_path(name)).lower(ctx)
+        info = ctx.scene_info()
+        assert info["leaves"] == leaves and info["csg_capacity"] == csg_cap, (name, info)
+
+
+def test_host_only_context_never_renders():
+    ctx = ft.Context(host_only=True)
+    H.single_prim(ctx, "sphere")
+    cam = ft.make_camera((0, 0, -5), (0, 0, 0), (0, 1, 0), 1.0)
+    with pytest.raises(ft.FtError) as e:
+        ctx.render(cam, 8, 8, 1, ft.jitter_pattern(1))
+    assert e.value.status == -2                               # FT_ERR_NO_DEVICE: no CPU fallback
+    with pytest.raises(ft.FtError):
+        ctx.closest([[0, 0, -5]], [[0, 0, 1]])
+
+
+def test_unsupported_surface_is_rejected_loudly():
+    ctx = ft.Context(host_only=True)
+    ctx.clear()
+    ctx.set_objects(ctx.group([ctx.material(ctx.primitive(ft.SPHERE), roughness=0.4)]))
+    with pytest.raises(ft.FtError) as e:
+        ctx.commit()
+    assert e.value.status == -4
+    with pytest.raises(ft.FtError):
+        ctx.primitive(99)
+    with pytest.raises(ft.FtError):
+        ctx.csg(ft.UNION, 12345, 0)
+
+
+def test_jitter_pattern_rule():                               # Jitter.fs:15-24: unit disc by rejection, reproducible stream
+    a, b = ft.jitter_pattern(64), ft.jitter_pattern(64)
+    assert np.array_equal(a, b) and (np.hypot(a[:, 0], a[:, 1]) <= 1.0).all()
+    assert not np.array_equal(a, ft.jitter_pattern(64, seed=1))
+    assert np.array_equal(ft.jitter_pattern(16), a[:16])
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(H.ROOT, "include", "functracer_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(ft_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    lib = C.CDLL(ft.HIP_LIB)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.ft_abi_version.restype = C.c_int32
+    assert lib.ft_abi_version() == 1
+    # no CPU backend: zero devices is an error, not an oracle-backed context (SURVEY 8b proposed one; the product has none)
+    h = C.c_void_p()
+    assert lib.ft_create(None, 0, C.byref(h)) == -2 and not h.value
+
+
+def test_product_library_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["ldd", ft.HIP_LIB], capture_output=True, text=True).stdout + subprocess.run(["nm", "-D", ft.HIP_LIB], capture_output=True, text=True).stdout
+    assert "ft_oracle" not in out and "fto_" not in out
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from PIL import Image
+    rgba = (np.arange(7 * 5 * 4) % 251).astype(np.uint8).reshape(5, 7, 4)
+    rgba[..., 3] = 255
+    path = tmp_path / "x.png"
+    ft.write_png(path, rgba)
+    assert np.array_equal(np.asarray(Image.open(path).convert("RGBA")), rgba)
