@@ -38,7 +38,7 @@ struct ft_context {
     int64_t chunk_samples = 8ll << 20;
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
@@ -169,7 +169,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -294,6 +294,7 @@ int32_t ft_scene_commit(ft_context* c) {
     if ((rc = upload(c, c->d_nodes, f.nodes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_bleaves, f.bsp_leaves)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tris, f.tris)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_culls, f.culls)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters))) != FT_OK) return rc;
     FT_HIP(c, hipStreamSynchronize(c->stream));
@@ -301,7 +302,7 @@ int32_t ft_scene_commit(ft_context* c) {
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
     S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>();
     S.program = c->d_program.as<uint32_t>(); S.meshes = c->d_meshes.as<ftd::Mesh>();
-    S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>();
+    S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>();
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
     c->committed = true;

@@ -86,7 +86,21 @@ enum Op : uint32_t {
     OP_LEAF_PUSH = 2,      // intersect leaf, append hits to the per-lane hit list (inside a CSG subtree)
     OP_MARK = 3,           // push the current list length (start of an operand segment)
     OP_CSG = 4,            // merge the two topmost segments with rule table arg (ft_csg_op)
-    OP_FOLD_LIST = 5       // fold the per-lane list into closest / any-hit and clear it
+    OP_FOLD_LIST = 5,      // fold the per-lane list into closest / any-hit and clear it
+    OP_CULL = 6            // arg = cull record; next word = number of program words of the item that follows.
+                           // If no lane of the wave can possibly hit the item, the item is skipped.
+};
+
+// Conservative bound of one top-level item (a leaf or an outermost CSG subtree), 24 doubles.
+// Skipping is exact: the line misses an inflated bounding sphere of every leaf box of the item, AND the
+// ray is not near-parallel to any plane-derived face of it (Plane.intersect's parallel-ray rule,
+// Plane.fs:13-16, can return a hit at the ray origin wherever that origin is).
+struct CullRecord {
+    double centre[3];
+    double radius2;        // (r * (1 + 1e-6) + 1e-9)^2
+    double n_rows;         // number of parallel-sensitive directions, <= 6
+    double rows[6][3];     // world-space rows of world->model matrices whose dot with d is a plane denominator
+    double pad;
 };
 inline uint32_t make_op(uint32_t op, uint32_t arg) { return op | (arg << 8); }
 

@@ -32,6 +32,53 @@ namespace {
 constexpr double kEps = 0.0000001;
 constexpr int kDone = INT32_MIN;
 
+// Scene data is immutable for the lifetime of a launch.  Reading it through constant-address-space
+// pointers lets the compiler use scalar loads (s_load_*, SGPR operands) for every wave-uniform
+// access even though the kernels also store to global memory; with generic pointers it falls back to
+// per-lane global_load of the same address.
+#define FT_CONST __attribute__((address_space(4)))
+typedef const FT_CONST double* cdp;
+typedef const FT_CONST uint32_t* cup;
+typedef const FT_CONST int32_t* cip;
+template <class T> FT_DEV const FT_CONST T* to_const_as(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const FT_CONST T*)p;
+#pragma clang diagnostic pop
+}
+struct Scene {
+    cdp leaves;       // 16 doubles per leaf (ftd::Leaf)
+    cdp m2w;          // 12 per leaf
+    cdp materials;    // 8 doubles per ftd::Material
+    cdp lights;       // 12 doubles per ftd::Light
+    cup program;
+    cip meshes;       // 4 words per ftd::Mesh
+    cdp nodes;        // 8 doubles per ftd::BspNode
+    cup bsp_leaves;   // 2 words per ftd::BspLeaf
+    cdp tris;         // 9 doubles per triangle
+    cdp culls;        // 24 doubles per ftd::CullRecord
+    int32_t n_leaves, n_lights, csg_cap, stack_cap;
+};
+static_assert(sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
+FT_DEV Scene scene_view(const DevScene& g) {
+    Scene s;
+    s.leaves = to_const_as(g.leaves); s.m2w = to_const_as(g.m2w);
+    s.materials = to_const_as(reinterpret_cast<const double*>(g.materials)); s.lights = to_const_as(reinterpret_cast<const double*>(g.lights));
+    s.program = to_const_as(g.program); s.meshes = to_const_as(reinterpret_cast<const int32_t*>(g.meshes));
+    s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
+    s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls);
+    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
+    return s;
+}
+struct MaterialV { double colour[3]; double roughness, reflectance, shineyness; uint32_t apply_lighting; };
+FT_DEV MaterialV material_at(const Scene& S, uint32_t i) {
+    cdp m = S.materials + 8ull * i;
+    MaterialV v;
+    v.colour[0] = m[0]; v.colour[1] = m[1]; v.colour[2] = m[2]; v.roughness = m[3]; v.reflectance = m[4]; v.shineyness = m[5];
+    v.apply_lighting = reinterpret_cast<cup>(m + 6)[0];
+    return v;
+}
+
 struct Ray { double ox, oy, oz, dx, dy, dz; };
 struct V3 { double x, y, z; };
 
@@ -144,7 +191,7 @@ FT_DEV bool plane_t(double num, double den, double& t) {
 // Möller–Trumbore (Triangle.fs:43-66) against v0,e1,e2.  The u / v range tests are decided without the
 // division whenever the outcome cannot depend on its rounding; the surviving lanes run the
 // reference's exact sequence.
-FT_DEV bool tri_hit(const double* __restrict__ T, const Ray& r, double& t_out) {
+FT_DEV bool tri_hit(cdp T, const Ray& r, double& t_out) {
     const double v0x = T[0], v0y = T[1], v0z = T[2], e1x = T[3], e1y = T[4], e1z = T[5], e2x = T[6], e2y = T[7], e2z = T[8];
     const double hx = r.dy * e2z - r.dz * e2y, hy = e2x * r.dz - e2z * r.dx, hz = r.dx * e2y - r.dy * e2x;   // ray.d .** edge2
     const double a = e1x * hx + e1y * hy + e1z * hz;
@@ -168,7 +215,8 @@ FT_DEV bool tri_hit(const double* __restrict__ T, const Ray& r, double& t_out) {
 }
 
 // BoundingBox.intersects (BoundingBox.fs:32-58), inverse direction precomputed per ray.
-FT_DEV bool aabb_hit(const BspNode& n, const Ray& r, double ivx, double ivy, double ivz) {
+FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz) {
+    struct { double bmin[3], bmax[3]; } n = {{nd[0], nd[1], nd[2]}, {nd[3], nd[4], nd[5]}};
     const bool nx = ivx < 0.0, ny = ivy < 0.0, nz = ivz < 0.0;
     double tmin = ((nx ? n.bmax[0] : n.bmin[0]) - r.ox) * ivx;
     double tmax = ((nx ? n.bmin[0] : n.bmax[0]) - r.ox) * ivx;
@@ -186,14 +234,14 @@ FT_DEV bool aabb_hit(const BspNode& n, const Ray& r, double ivx, double ivy, dou
 }
 
 template <class Emit>
-FT_DEV void mesh_hits(const DevScene& S, uint32_t mesh_idx, const Ray& r, bool active, int32_t* stack, Emit&& emit) {
-    const Mesh mesh = S.meshes[mesh_idx];
-    if (mesh.root < 0) {                                           // top-level Leaf: brute force, no AABB (BspMesh.fs:95-97)
-        const BspLeaf lf = S.bsp_leaves[~mesh.root];
-        const double* __restrict__ T = S.tris + 9ull * lf.first_tri;
-        for (uint32_t k = 0; k < lf.n_tris; ++k, T += 9) {         // wave-uniform loop: triangle data comes through scalar loads
+FT_DEV void mesh_hits(const Scene& S, uint32_t mesh_idx, const Ray& r, bool active, int32_t* stack, Emit&& emit) {
+    const int32_t root = S.meshes[4 * mesh_idx];
+    if (root < 0) {                                                // top-level Leaf: brute force, no AABB (BspMesh.fs:95-97)
+        const uint32_t first = S.bsp_leaves[2 * (~root)], count = S.bsp_leaves[2 * (~root) + 1];
+        cdp T = S.tris + 9ull * first;
+        for (uint32_t k = 0; k < count; ++k, T += 9) {             // wave-uniform loop: triangle data comes through scalar loads
             double t;
-            if (tri_hit(T, r, t)) emit(t, 0u, lf.first_tri + k);
+            if (tri_hit(T, r, t)) emit(t, 0u, first + k);
         }
         return;
     }
@@ -202,26 +250,26 @@ FT_DEV void mesh_hits(const DevScene& S, uint32_t mesh_idx, const Ray& r, bool a
     // LDS stack.
     const double ivx = 1.0 / r.dx, ivy = 1.0 / r.dy, ivz = 1.0 / r.dz;
     int sp = 0;
-    int cur = active ? mesh.root : kDone;
+    int cur = active ? root : kDone;
     while (__any(cur != kDone)) {
         while (cur >= 0) {                                         // descend through branches
-            const BspNode& n = S.nodes[cur];
-            if (aabb_hit(n, r, ivx, ivy, ivz)) { stack[sp * kBlock] = n.left; ++sp; cur = n.right; }
+            cdp nd = S.nodes + 8ull * (uint32_t)cur;
+            if (aabb_hit(nd, r, ivx, ivy, ivz)) { cip ch = reinterpret_cast<cip>(nd + 6); stack[sp * kBlock] = ch[0]; ++sp; cur = ch[1]; }
             else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
             else cur = kDone;
         }
         if (cur != kDone) {                                        // a leaf: every triangle, in list order
-            const BspLeaf lf = S.bsp_leaves[~cur];
-            for (uint32_t k = 0; k < lf.n_tris; ++k) {
+            const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
+            for (uint32_t k = 0; k < count; ++k) {
                 double t;
-                if (tri_hit(S.tris + 9ull * (lf.first_tri + k), r, t)) emit(t, 0u, lf.first_tri + k);
+                if (tri_hit(S.tris + 9ull * (first + k), r, t)) emit(t, 0u, first + k);
             }
             if (sp > 0) { --sp; cur = stack[sp * kBlock]; } else cur = kDone;
         }
     }
 }
 
-FT_DEV void to_model(const double* __restrict__ M, bool xform, const Ray& r, Ray& m) {   // Transform.fs:85
+FT_DEV void to_model(cdp M, bool xform, const Ray& r, Ray& m) {   // Transform.fs:85
     if (xform) {
         m.ox = M[0] * r.ox + M[1] * r.oy + M[2] * r.oz + M[3];
         m.oy = M[4] * r.ox + M[5] * r.oy + M[6] * r.oz + M[7];
@@ -233,8 +281,8 @@ FT_DEV void to_model(const double* __restrict__ M, bool xform, const Ray& r, Ray
 }
 
 struct LeafHead { uint32_t kind, flags, material, mesh; };
-FT_DEV LeafHead leaf_head(const DevScene& S, uint32_t leaf) {
-    const uint32_t* h = reinterpret_cast<const uint32_t*>(S.leaves + 16ull * leaf + 12);
+FT_DEV LeafHead leaf_head(const Scene& S, uint32_t leaf) {
+    cup h = reinterpret_cast<cup>(S.leaves + 16ull * leaf + 12);
     return {h[0], h[1], h[2], h[3]};
 }
 
@@ -248,7 +296,7 @@ FT_DEV bool quadratic(double a, double b, double c, double& r0, double& r1) {
 }
 
 template <class Emit>
-FT_DEV void leaf_hits(const DevScene& S, uint32_t leaf, const LeafHead& H, const Ray& rw, bool active, int32_t* stack, Emit&& emit) {
+FT_DEV void leaf_hits(const Scene& S, uint32_t leaf, const LeafHead& H, const Ray& rw, bool active, int32_t* stack, Emit&& emit) {
     Ray r;
     to_model(S.leaves + 16ull * leaf, (H.flags & LF_XFORM) != 0, rw, r);
     switch (H.kind) {                                              // wave-uniform
@@ -343,7 +391,7 @@ FT_DEV void leaf_hits(const DevScene& S, uint32_t leaf, const LeafHead& H, const
 // ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
 template <bool ANY>
-FT_DEV void trace(const DevScene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow) {
+FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow) {
     HitList L;
     L.init(lds, S.csg_cap);
     int32_t* stack = reinterpret_cast<int32_t*>(lds + 4 * S.csg_cap * kBlock) + threadIdx.x;
@@ -361,6 +409,22 @@ FT_DEV void trace(const DevScene& S, const Ray& r, Query<ANY>& q, uint32_t* lds,
             case OP_LEAF_PUSH: {
                 const LeafHead H = leaf_head(S, arg);
                 leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { if (q.active) L.push(t, arg | (sub << ID_SUB_SHIFT), tri); });
+                break;
+            }
+            case OP_CULL: {
+                // Exact skip of a whole item: taken only when NO lane of the wave can produce a hit on it.
+                cdp C = S.culls + 24ull * arg;
+                const double ocx = r.ox - C[0], ocy = r.oy - C[1], ocz = r.oz - C[2];
+                const double dd = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz), b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz), cc = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
+                // squared distance from the centre to the ray's LINE exceeds the inflated radius (negative t matters under CSG)
+                bool miss = (cc * dd - b * b) > (C[3] * dd + 1e-12 * (cc * dd)) && dd > 0.0;
+                const int n_rows = (int)C[4];
+                for (int k = 0; k < n_rows; ++k)                   // near-parallel to a plane-derived face: Plane.fs:13-16 may hit at the origin
+                    if (fabs(dot3(C[5 + 3 * k], C[6 + 3 * k], C[7 + 3 * k], r.dx, r.dy, r.dz)) < 2.0 * kEps) miss = false;
+                bool need = q.active && !miss;
+                if (ANY) need = need && !q.blocked;
+                ++pc;
+                if (!__any(need)) pc += S.program[pc];
                 break;
             }
             case OP_MARK: L.mark(); break;
@@ -391,10 +455,10 @@ FT_DEV void cylinder_side(const Ray& r, double t, V3& p, V3& n) {   // Cylinder.
     n = (dot3(nn.x, nn.y, nn.z, r.dx, r.dy, r.dz) < 0.0) ? nn : V3{-nn.x, -nn.y, -nn.z};
 }
 
-FT_DEV Surface surface_at(const DevScene& S, const Ray& rw, double t, uint32_t id0, uint32_t id1) {
+FT_DEV Surface surface_at(const Scene& S, const Ray& rw, double t, uint32_t id0, uint32_t id1) {
     const uint32_t leaf = id0 & ID_LEAF_MASK, sub = (id0 >> ID_SUB_SHIFT) & ID_SUB_MASK;
     const LeafHead H = leaf_head(S, leaf);
-    const double* __restrict__ M = S.leaves + 16ull * leaf;
+    cdp M = S.leaves + 16ull * leaf;
     const bool xform = (H.flags & LF_XFORM) != 0;
     Ray r;
     to_model(M, xform, rw, r);
@@ -424,7 +488,7 @@ FT_DEV Surface surface_at(const DevScene& S, const Ray& rw, double t, uint32_t i
             break;
         }
         default: {                                                 // triangle (Triangle.fs:63-64)
-            const double* __restrict__ T = S.tris + 9ull * id1;
+            cdp T = S.tris + 9ull * id1;
             const double len = sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
             const V3 nd = normalise(V3{r.dx, r.dy, r.dz});
             const double k = t * len;
@@ -434,7 +498,7 @@ FT_DEV Surface surface_at(const DevScene& S, const Ray& rw, double t, uint32_t i
         }
     }
     if (xform) {                                                   // Transform.fs:86: p <- modelToWorld*p, n <- normalise(normalToWorld*n)
-        const double* __restrict__ W = S.m2w + 12ull * leaf;
+        cdp W = S.m2w + 12ull * leaf;
         p = {W[0] * p.x + W[1] * p.y + W[2] * p.z + W[3], W[4] * p.x + W[5] * p.y + W[6] * p.z + W[7], W[8] * p.x + W[9] * p.y + W[10] * p.z + W[11]};
         n = normalise(V3{M[0] * n.x + M[4] * n.y + M[8] * n.z, M[1] * n.x + M[5] * n.y + M[9] * n.z, M[2] * n.x + M[6] * n.y + M[10] * n.z});   // (W2M^T) n
     }
@@ -476,9 +540,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(Camera cam, const uint32_t*
     if (blockIdx.x == 0 && threadIdx.x == 0) cc->n_rays[0] = n;
 }
 
-__global__ __launch_bounds__(kBlock) void k_closest(DevScene S, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
+__global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
                                                      ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const Scene S = scene_view(Sg);
     const uint32_t n = cc->n_rays[bounce];
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
     for (;;) {
@@ -510,10 +575,11 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene S, RayBuf rays, Hit
     wave_add(&rc->csg_overflow, n_ovf_wave);
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
                                                    double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
                                                    ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const Scene S = scene_view(Sg);
     const uint32_t n = cc->n_hits[bounce];
     const int n_lights = S.n_lights;
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
@@ -534,13 +600,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RayBuf rays, HitBu
         const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
         Surface sf{{0, 0, 0}, {0, 1, 0}, 0};
         if (active) sf = surface_at(S, ro, t, id0, id1);
-        const Material mat = S.materials[sf.material];             // per-lane gather (64 B records, L1/L2 resident)
+        const MaterialV mat = material_at(S, sf.material);            // per-lane gather (64 B records, L1/L2 resident)
         const bool lit = active && mat.apply_lighting != 0;
         double cr = 0.0, cg = 0.0, cb = 0.0;                       // sum over fragments (Seq.sumBy shader, Shading.fs:139)
         // getLightsOnPoint (Shading.fs:109-117)
         const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
         for (int l = 0; l < n_lights; ++l) {                       // wave-uniform
-            const Light& lt = S.lights[l];
+            cdp lp = S.lights + 12ull * (uint32_t)l;                 // wave-uniform: scalar loads
+            struct { double v[3], falloff[3], colour[3]; uint32_t kind; } lt = {{lp[0], lp[1], lp[2]}, {lp[3], lp[4], lp[5]}, {lp[6], lp[7], lp[8]}, reinterpret_cast<cup>(lp + 10)[0]};
             if (active && !lit) { cr += mat.colour[0]; cg += mat.colour[1]; cb += mat.colour[2]; }   // shadeIfRequired (Shading.fs:100-104)
             Query<true> q;
             q.active = lit; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0;
@@ -627,9 +694,10 @@ __global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene S, const double* __restrict__ o, const double* __restrict__ d, uint32_t n,
+__global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene Sg, const double* __restrict__ o, const double* __restrict__ d, uint32_t n,
                                                            int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const Scene S = scene_view(Sg);
     const uint32_t n_batches = (n + 63) / 64;
     for (uint32_t b = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; b < n_batches; b += gridDim.x * (kBlock / 64)) {
         const uint32_t i = b * 64 + lane_id();
@@ -644,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene S, const doub
             hit[i] = h ? 1 : 0;
             Surface sf{{0, 0, 0}, {1, 0, 0}, 0};
             double col[3] = {1, 1, 1};
-            if (h) { sf = surface_at(S, r, q.best_t, q.id0, q.id1); const Material m = S.materials[sf.material]; col[0] = m.colour[0]; col[1] = m.colour[1]; col[2] = m.colour[2]; }
+            if (h) { sf = surface_at(S, r, q.best_t, q.id0, q.id1); const MaterialV m = material_at(S, sf.material); col[0] = m.colour[0]; col[1] = m.colour[1]; col[2] = m.colour[2]; }
             t[i] = h ? q.best_t : 0.0;
             p[3 * i] = sf.p.x; p[3 * i + 1] = sf.p.y; p[3 * i + 2] = sf.p.z;
             nrm[3 * i] = sf.n.x; nrm[3 * i + 1] = sf.n.y; nrm[3 * i + 2] = sf.n.z;
@@ -654,9 +722,10 @@ __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene S, const doub
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene S, const double* __restrict__ o, const double* __restrict__ d,
+__global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const double* __restrict__ o, const double* __restrict__ d,
                                                            const double* __restrict__ max_dist, uint32_t n, int32_t* blocked, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const Scene S = scene_view(Sg);
     const uint32_t n_batches = (n + 63) / 64;
     for (uint32_t b = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; b < n_batches; b += gridDim.x * (kBlock / 64)) {
         const uint32_t i = b * 64 + lane_id();

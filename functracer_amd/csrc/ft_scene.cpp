@@ -2,6 +2,7 @@
 // Reference citations are relative to /root/reference/FuncTracer/.
 #include "ft_scene.h"
 
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -149,10 +150,80 @@ struct Flattener {
         int32_t rc = build_bsp(tris, n, depth, out, m, err);
         if (rc != FT_OK) { status = rc; return 0; }
         out.meshes.push_back(m);
+        {
+            const double inf = std::numeric_limits<double>::infinity();
+            double b[6] = {inf, inf, inf, -inf, -inf, -inf};
+            for (int64_t i = 0; i < 3 * n; ++i) for (int a = 0; a < 3; ++a) { double v = tris[3 * i + a]; if (v < b[a]) b[a] = v; if (v > b[3 + a]) b[3 + a] = v; }
+            out.mesh_bounds.insert(out.mesh_bounds.end(), b, b + 6);
+        }
         uint32_t idx = (uint32_t)out.meshes.size() - 1;
         if (node_id >= 0) mesh_of_node[node_id] = idx;
         if ((int32_t)m.max_depth + 1 > out.stack_capacity && m.root >= 0) out.stack_capacity = (int32_t)m.max_depth + 1;
         return idx;
+    }
+
+    // ---- top-level item culling -------------------------------------------------------------
+    struct ItemMark { size_t prog_at, leaf_at; bool open; };
+    ItemMark begin_item(bool in_csg) {
+        if (in_csg) return {0, 0, false};
+        ItemMark m{out.program.size(), out.leaves.size(), true};
+        out.program.push_back(ftd::make_op(ftd::OP_CULL, 0));
+        out.program.push_back(0);
+        return m;
+    }
+    bool model_box(const ftd::Leaf& L, double lo[3], double hi[3]) const {
+        switch (L.kind) {
+            case ftd::LK_SPHERE: lo[0] = lo[1] = lo[2] = -1; hi[0] = hi[1] = hi[2] = 1; return true;
+            case ftd::LK_SQUARE: lo[0] = 0; lo[1] = 0; lo[2] = 0; hi[0] = 1; hi[1] = 0; hi[2] = 1; return true;
+            case ftd::LK_CIRCLE: lo[0] = -1; lo[1] = 0; lo[2] = -1; hi[0] = 1; hi[1] = 0; hi[2] = 1; return true;
+            case ftd::LK_CUBE: lo[0] = lo[1] = lo[2] = -0.5; hi[0] = hi[1] = hi[2] = 0.5; return true;
+            case ftd::LK_CONE: case ftd::LK_CYLINDER: case ftd::LK_SOLIDCYL: lo[0] = -1; lo[1] = 0; lo[2] = -1; hi[0] = 1; hi[1] = 1; hi[2] = 1; return true;
+            case ftd::LK_MESH: {
+                const double* b = &out.mesh_bounds[6 * (size_t)L.mesh];
+                for (int a = 0; a < 3; ++a) { lo[a] = b[a]; hi[a] = b[3 + a]; }
+                return lo[0] <= hi[0];
+            }
+            default: return false;                                  // LK_PLANE: unbounded
+        }
+    }
+    void end_item(const ItemMark& m) {
+        if (!m.open) return;
+        auto drop = [&]() { out.program.erase(out.program.begin() + (long)m.prog_at, out.program.begin() + (long)m.prog_at + 2); };
+        if (status != FT_OK || out.leaves.size() == m.leaf_at) { drop(); return; }
+        const double inf = std::numeric_limits<double>::infinity();
+        double blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
+        std::vector<std::array<double, 3>> pts, rows;
+        for (size_t li = m.leaf_at; li < out.leaves.size(); ++li) {
+            const ftd::Leaf& L = out.leaves[li];
+            double lo[3], hi[3];
+            if (!model_box(L, lo, hi)) { drop(); return; }
+            const double* W = &out.m2w[12 * li];
+            for (int corner = 0; corner < 8; ++corner) {
+                const double x = (corner & 1) ? hi[0] : lo[0], y = (corner & 2) ? hi[1] : lo[1], z = (corner & 4) ? hi[2] : lo[2];
+                std::array<double, 3> q = {W[0] * x + W[1] * y + W[2] * z + W[3], W[4] * x + W[5] * y + W[6] * z + W[7], W[8] * x + W[9] * y + W[10] * z + W[11]};
+                for (int a = 0; a < 3; ++a) { if (!(std::fabs(q[a]) < 1e300)) { drop(); return; } if (q[a] < blo[a]) blo[a] = q[a]; if (q[a] > bhi[a]) bhi[a] = q[a]; }
+                pts.push_back(q);
+            }
+            auto add_row = [&](int r) {                             // world-space vector whose dot with d is a plane denominator of this leaf
+                std::array<double, 3> v = {L.w2m[4 * r], L.w2m[4 * r + 1], L.w2m[4 * r + 2]};
+                for (auto& e : rows) if (e == v) return;
+                rows.push_back(v);
+            };
+            if (L.kind == ftd::LK_SQUARE || L.kind == ftd::LK_CIRCLE || L.kind == ftd::LK_SOLIDCYL) add_row(1);
+            if (L.kind == ftd::LK_CUBE) { add_row(0); add_row(1); add_row(2); }
+        }
+        if (rows.size() > 6) { drop(); return; }
+        ftd::CullRecord R{};
+        double r2 = 0.0;
+        for (int a = 0; a < 3; ++a) R.centre[a] = 0.5 * (blo[a] + bhi[a]);
+        for (auto& q : pts) { double d2 = 0; for (int a = 0; a < 3; ++a) d2 += (q[a] - R.centre[a]) * (q[a] - R.centre[a]); if (d2 > r2) r2 = d2; }
+        const double r = std::sqrt(r2) * (1.0 + 1e-6) + 1e-9;
+        R.radius2 = r * r;
+        R.n_rows = (double)rows.size();
+        for (size_t k = 0; k < rows.size(); ++k) for (int a = 0; a < 3; ++a) R.rows[k][a] = rows[k][a];
+        out.culls.push_back(R);
+        out.program[m.prog_at] = ftd::make_op(ftd::OP_CULL, (uint32_t)out.culls.size() - 1);
+        out.program[m.prog_at + 1] = (uint32_t)(out.program.size() - (m.prog_at + 2));
     }
 
     void walk(int32_t id, const WalkCtx& c, bool in_csg) {
@@ -162,20 +233,26 @@ struct Flattener {
             case GraphNode::Prim: {
                 static const uint32_t kind_of[8] = {ftd::LK_CIRCLE, ftd::LK_SQUARE, ftd::LK_CUBE, ftd::LK_SPHERE, ftd::LK_PLANE, ftd::LK_CONE, ftd::LK_SOLIDCYL, ftd::LK_CYLINDER};
                 static const int max_hits[8] = {1, 1, 6, 2, 1, 2, 4, 2};
+                ItemMark im = begin_item(in_csg);
                 emit_leaf(kind_of[n.prim], 0, c, false, in_csg, max_hits[n.prim]);
+                end_item(im);
                 break;
             }
             case GraphNode::TriangleP: {
                 uint32_t mesh = mesh_for(-1, n.tri, 1, 0);
+                ItemMark im = begin_item(in_csg);
                 if (status == FT_OK) emit_leaf(ftd::LK_MESH, mesh, c, false, in_csg, 1);
+                end_item(im);
                 break;
             }
             case GraphNode::Mesh: {
                 uint32_t mesh = mesh_for(id, n.tris.data(), (int64_t)(n.tris.size() / 9), n.depth);
+                ItemMark im = begin_item(in_csg);
                 if (status == FT_OK) {
                     if (in_csg) out.mesh_under_csg = true;
                     emit_leaf(ftd::LK_MESH, mesh, c, false, in_csg, g.csg_mesh_capacity);
                 }
+                end_item(im);
                 break;
             }
             case GraphNode::Transform: {
@@ -206,7 +283,9 @@ struct Flattener {
                             const double* t = g.nodes[n.children[i]].tri; run.insert(run.end(), t, t + 9); ++i;
                         }
                         uint32_t mesh = mesh_for(-1, run.data(), (int64_t)(run.size() / 9), 0);
+                        ItemMark im = begin_item(in_csg);
                         if (status == FT_OK) emit_leaf(ftd::LK_MESH, mesh, c, false, in_csg, (int)std::min<size_t>(run.size() / 9, (size_t)g.csg_mesh_capacity));
+                        end_item(im);
                     } else {
                         walk(n.children[i], c, in_csg); ++i;
                     }
@@ -216,6 +295,7 @@ struct Flattener {
             case GraphNode::Csg: {
                 ++csg_depth; if (csg_depth > max_csg_depth) max_csg_depth = csg_depth;
                 int before = cur_list;
+                ItemMark im = begin_item(in_csg);
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
                 walk(n.children[0], c, true);
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
@@ -223,6 +303,7 @@ struct Flattener {
                 out.program.push_back(ftd::make_op(ftd::OP_CSG, (uint32_t)n.op));
                 --csg_depth;
                 if (!in_csg) { out.program.push_back(ftd::make_op(ftd::OP_FOLD_LIST, 0)); cur_list = before; }
+                end_item(im);
                 break;
             }
         }
@@ -248,6 +329,7 @@ int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
     for (auto& m : out.materials) if (m.roughness != 0.0) { err = "roughness != 0 (Oren-Nayar, Shading.fs:50-63) is not on the device path yet"; return FT_ERR_UNSUPPORTED; }
     for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) { err = "softdirectional lights are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
     if (out.tris.empty()) out.tris.assign(9, 0.0);   // keep device pointers non-null
+    if (out.culls.empty()) out.culls.push_back(ftd::CullRecord{});
     return FT_OK;
 }
 

@@ -35,6 +35,8 @@ struct FlatScene {
     std::vector<ftd::BspNode> nodes;
     std::vector<ftd::BspLeaf> bsp_leaves;
     std::vector<double> tris;         // 9 per triangle: v0, e1, e2
+    std::vector<ftd::CullRecord> culls;
+    std::vector<double> mesh_bounds;  // 6 per mesh: model-space AABB of the source triangles (lo > hi when empty)
     int32_t csg_capacity = 0;         // per-lane hit-list entries needed (0 = scene has no CSG)
     int32_t stack_capacity = 0;       // per-lane BSP stack entries needed (0 = no BSP branches)
     bool any_reflective = false;
