@@ -38,7 +38,7 @@ struct ft_context {
     int64_t chunk_samples = 8ll << 20;
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
@@ -169,7 +169,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -295,6 +295,7 @@ int32_t ft_scene_commit(ft_context* c) {
     if ((rc = upload(c, c->d_bleaves, f.bsp_leaves)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tris, f.tris)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_culls, f.culls)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters))) != FT_OK) return rc;
     FT_HIP(c, hipStreamSynchronize(c->stream));
@@ -302,7 +303,7 @@ int32_t ft_scene_commit(ft_context* c) {
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
     S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>();
     S.program = c->d_program.as<uint32_t>(); S.meshes = c->d_meshes.as<ftd::Mesh>();
-    S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>();
+    S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>(); S.tri_orig = c->d_tri_orig.as<uint32_t>();
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
     c->committed = true;
@@ -505,8 +506,8 @@ int32_t ft_debug_scene_info(ft_context* c, int64_t out[8]) {
     if (!c || !out) return FT_ERR_INVALID;
     if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }
     const fth::FlatScene& f = c->flat;
-    out[0] = (int64_t)f.leaves.size(); out[1] = (int64_t)f.program.size(); out[2] = (int64_t)f.meshes.size(); out[3] = (int64_t)f.nodes.size();
-    out[4] = (int64_t)f.bsp_leaves.size(); out[5] = (int64_t)(f.tris.size() / 9); out[6] = f.csg_capacity; out[7] = f.stack_capacity;
+    out[0] = (int64_t)f.leaves.size(); out[1] = (int64_t)f.program.size(); out[2] = (int64_t)f.meshes.size(); out[3] = (int64_t)f.nodes.size() - f.bvh_nodes;
+    out[4] = (int64_t)f.bsp_leaves.size() - f.bvh_leaves; out[5] = (int64_t)(f.tris.size() / 9) - f.bvh_tris; out[6] = f.csg_capacity; out[7] = f.bsp_stack_capacity;   // BSP-only: excludes the device-side BVH
     return FT_OK;
 }
 

@@ -23,6 +23,7 @@ struct DevScene {
     const ftd::BspLeaf* bsp_leaves;
     const double* tris;            // 9 per triangle: v0, e1, e2
     const double* culls;           // 24 doubles per ftd::CullRecord
+    const uint32_t* tri_orig;      // 1 per triangle
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
 };
 

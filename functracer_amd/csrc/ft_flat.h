@@ -69,15 +69,24 @@ struct Mesh {
     int32_t root;          // >= 0: BSP branch node index; < 0: ~leaf index (top-level Leaf, brute force, no AABB)
     uint32_t n_source_tris;
     uint32_t max_depth;    // BspMesh.maxDepth of the compiled tree
-    uint32_t pad;
+    int32_t bvh_root;      // top-level-Leaf meshes only: root of the device-side BVH (>= 0 node, < 0 ~leaf), or INT32_MIN = none
 };
-struct BspNode {           // 64 bytes; BspMesh.fs:12-19
+struct BspNode {           // 64 bytes; BspMesh.fs:12-19 (also used for BVH nodes)
     double bmin[3], bmax[3];
     int32_t left, right;   // >= 0 branch node; < 0: ~leaf index
-    uint32_t pad[2];
+    uint32_t axis;         // BVH nodes: split axis (left = lower centroids)
+    uint32_t pad;
 };
 struct BspLeaf { uint32_t first_tri, n_tris; };
 // Triangles: 9 doubles each = v0, edge1 = v1 - v0, edge2 = v2 - v0 (Triangle.fs:45-46 evaluated once on the host).
+// tri_orig[k] = index of the same triangle in the mesh's reference-order list (identity except inside BVH leaves).
+//
+// The BVH is an acceleration structure the reference does not have.  A top-level Leaf is "every triangle,
+// in list order" (BspMesh.fs:53, 95-97); closest-hit / any-hit over that list only depend on the set of hits
+// and, for equal t, on list order.  The BVH visits the ORIGINAL (unclipped) triangles with the same
+// per-triangle arithmetic, prunes only boxes that cannot hold a closer hit (boxes are inflated, so rounding
+// cannot prune a real hit) and breaks t ties by list index, so the result is identical to the linear scan.
+// Hit lists under CSG still use the linear scan (order matters there).
 
 // Program words: opcode in the low 8 bits, argument in the high 24.
 enum Op : uint32_t {

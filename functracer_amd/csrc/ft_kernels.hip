@@ -57,6 +57,7 @@ struct Scene {
     cup bsp_leaves;   // 2 words per ftd::BspLeaf
     cdp tris;         // 9 doubles per triangle
     cdp culls;        // 24 doubles per ftd::CullRecord
+    cup tri_orig;     // 1 per triangle
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
 };
 static_assert(sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
@@ -66,7 +67,7 @@ FT_DEV Scene scene_view(const DevScene& g) {
     s.materials = to_const_as(reinterpret_cast<const double*>(g.materials)); s.lights = to_const_as(reinterpret_cast<const double*>(g.lights));
     s.program = to_const_as(g.program); s.meshes = to_const_as(reinterpret_cast<const int32_t*>(g.meshes));
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
-    s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls);
+    s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig);
     s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
     return s;
 }
@@ -388,6 +389,52 @@ FT_DEV void leaf_hits(const Scene& S, uint32_t leaf, const LeafHead& H, const Ra
     }
 }
 
+// Closest / any-hit query of a top-level-Leaf mesh through the exact BVH (ft_flat.h): same per-triangle
+// arithmetic as the linear scan, boxes pruned only when they cannot hold a usable hit, t ties resolved
+// by list index.  `r` is the ray in the mesh's model space.
+template <bool ANY>
+FT_DEV void mesh_bvh_query(const Scene& S, int32_t bvh_root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit, int32_t* stack) {
+    const double ivx = 1.0 / r.dx, ivy = 1.0 / r.dy, ivz = 1.0 / r.dz;
+    double bound = ANY ? q.max_dist : q.best_t;                    // a hit at t >= bound cannot change the query's result
+    uint32_t best_tri = 0xFFFFFFFFu;
+    bool found = false;
+    int sp = 0;
+    int cur = (q.active && !(ANY && q.blocked)) ? bvh_root : kDone;
+    while (__any(cur != kDone)) {
+        while (cur >= 0) {
+            cdp nd = S.nodes + 8ull * (uint32_t)cur;
+            double t0 = (nd[0] - r.ox) * ivx, t1 = (nd[3] - r.ox) * ivx;
+            double tmin = fmin(t0, t1), tmax = fmax(t0, t1);       // fmin/fmax drop NaNs (0 * inf on a slab plane): conservative
+            t0 = (nd[1] - r.oy) * ivy; t1 = (nd[4] - r.oy) * ivy;
+            tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+            t0 = (nd[2] - r.oz) * ivz; t1 = (nd[5] - r.oz) * ivz;
+            tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+            if (tmax >= fmax(tmin, 0.0) && tmin <= bound) {        // triangle hits need t > 1e-7 (Triangle.fs:62), so boxes behind the origin are out
+                cip ch = reinterpret_cast<cip>(nd + 6);
+                const uint32_t axis = reinterpret_cast<cup>(nd + 7)[0];
+                const double da = axis == 0 ? r.dx : axis == 1 ? r.dy : r.dz;
+                const int near = da >= 0.0 ? ch[0] : ch[1], far = da >= 0.0 ? ch[1] : ch[0];
+                stack[sp * kBlock] = far; ++sp; cur = near;        // near child first: the bound shrinks sooner
+            } else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+            else cur = kDone;
+        }
+        if (cur != kDone) {
+            const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
+            for (uint32_t k = 0; k < count; ++k) {
+                double t;
+                if (!tri_hit(S.tris + 9ull * (first + k), r, t)) continue;
+                if (ANY) { if (t < bound) { q.blocked = true; sp = 0; break; } }
+                else {
+                    const uint32_t orig = S.tri_orig[first + k];
+                    if (t < bound || (found && t == bound && orig < best_tri)) { bound = t; best_tri = orig; found = true; }
+                }
+            }
+            if (sp > 0) { --sp; cur = stack[sp * kBlock]; } else cur = kDone;
+        }
+    }
+    if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
 template <bool ANY>
@@ -403,6 +450,16 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
             case OP_LEAF_FOLD: {
                 const LeafHead H = leaf_head(S, arg);
                 const bool lit = (H.flags & LF_LIT) != 0;
+                if (ANY && !lit) break;                            // an unlit object never blocks light (Scene.fs:121)
+                if (H.kind == LK_MESH) {
+                    const int32_t bvh = S.meshes[4 * H.mesh + 3];
+                    if (bvh >= 0) {
+                        Ray rm;
+                        to_model(S.leaves + 16ull * arg, (H.flags & LF_XFORM) != 0, r, rm);
+                        mesh_bvh_query<ANY>(S, bvh, rm, q, arg, lit, stack);
+                        break;
+                    }
+                }
                 leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { q.hit(t, arg | (sub << ID_SUB_SHIFT), tri, lit); });
                 break;
             }

@@ -2,6 +2,7 @@
 // Reference citations are relative to /root/reference/FuncTracer/.
 #include "ft_scene.h"
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstring>
@@ -159,6 +160,7 @@ struct Flattener {
         uint32_t idx = (uint32_t)out.meshes.size() - 1;
         if (node_id >= 0) mesh_of_node[node_id] = idx;
         if ((int32_t)m.max_depth + 1 > out.stack_capacity && m.root >= 0) out.stack_capacity = (int32_t)m.max_depth + 1;
+        if ((int32_t)m.max_depth + 1 > out.bsp_stack_capacity && m.root >= 0) out.bsp_stack_capacity = (int32_t)m.max_depth + 1;
         return idx;
     }
 
@@ -328,7 +330,7 @@ int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
     if (out.any_texture) { err = "textures (Scene.fs:44) are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
     for (auto& m : out.materials) if (m.roughness != 0.0) { err = "roughness != 0 (Oren-Nayar, Shading.fs:50-63) is not on the device path yet"; return FT_ERR_UNSUPPORTED; }
     for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) { err = "softdirectional lights are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
-    if (out.tris.empty()) out.tris.assign(9, 0.0);   // keep device pointers non-null
+    if (out.tris.empty()) { out.tris.assign(9, 0.0); out.tri_orig.assign(1, 0u); }   // keep device pointers non-null
     if (out.culls.empty()) out.culls.push_back(ftd::CullRecord{});
     return FT_OK;
 }
@@ -389,10 +391,74 @@ struct BspBuilder {
         ftd::BspLeaf L{(uint32_t)(out.tris.size() / 9), (uint32_t)ts.size()};
         for (auto& t : ts) {                                                    // v0, edge1, edge2 (Triangle.fs:45-46)
             const double rec[9] = {t.a.x, t.a.y, t.a.z, t.b.x - t.a.x, t.b.y - t.a.y, t.b.z - t.a.z, t.c.x - t.a.x, t.c.y - t.a.y, t.c.z - t.a.z};
+            out.tri_orig.push_back((uint32_t)(out.tris.size() / 9));
             out.tris.insert(out.tris.end(), rec, rec + 9);
         }
         out.bsp_leaves.push_back(L);
         return ~(int32_t)(out.bsp_leaves.size() - 1);
+    }
+
+    // ---- device-side BVH over the triangles of a top-level Leaf (see ft_flat.h) -----------------
+    struct Box { double lo[3], hi[3]; };
+    uint32_t bvh_depth = 0;
+    int32_t bvh_build(const std::vector<Tri3>& ts, const std::vector<Box>& boxes, std::vector<uint32_t>& idx, size_t lo, size_t hi,
+                      uint32_t first_global, double pad, uint32_t level) {
+        if (level + 1 > bvh_depth) bvh_depth = level + 1;
+        if (hi - lo <= 2) {                                                     // leaf: a reordered copy of the triangles + their list indices
+            ftd::BspLeaf L{(uint32_t)(out.tris.size() / 9), (uint32_t)(hi - lo)};
+            for (size_t k = lo; k < hi; ++k) {
+                const Tri3& t = ts[idx[k]];
+                const double rec[9] = {t.a.x, t.a.y, t.a.z, t.b.x - t.a.x, t.b.y - t.a.y, t.b.z - t.a.z, t.c.x - t.a.x, t.c.y - t.a.y, t.c.z - t.a.z};
+                out.tri_orig.push_back(first_global + idx[k]);
+                out.tris.insert(out.tris.end(), rec, rec + 9);
+            }
+            out.bsp_leaves.push_back(L);
+            return ~(int32_t)(out.bsp_leaves.size() - 1);
+        }
+        const double inf = std::numeric_limits<double>::infinity();
+        Box b{{inf, inf, inf}, {-inf, -inf, -inf}}, cb = b;
+        for (size_t k = lo; k < hi; ++k) {
+            const Box& t = boxes[idx[k]];
+            for (int a = 0; a < 3; ++a) {
+                if (t.lo[a] < b.lo[a]) b.lo[a] = t.lo[a];
+                if (t.hi[a] > b.hi[a]) b.hi[a] = t.hi[a];
+                const double c = 0.5 * (t.lo[a] + t.hi[a]);
+                if (c < cb.lo[a]) cb.lo[a] = c;
+                if (c > cb.hi[a]) cb.hi[a] = c;
+            }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+        const size_t mid = (lo + hi) / 2;
+        std::nth_element(idx.begin() + (long)lo, idx.begin() + (long)mid, idx.begin() + (long)hi, [&](uint32_t x, uint32_t y) {
+            const double cx = boxes[x].lo[axis] + boxes[x].hi[axis], cy = boxes[y].lo[axis] + boxes[y].hi[axis];
+            return cx < cy || (cx == cy && x < y);
+        });
+        const int32_t node = (int32_t)out.nodes.size();
+        out.nodes.push_back(ftd::BspNode{});
+        const int32_t l = bvh_build(ts, boxes, idx, lo, mid, first_global, pad, level + 1);
+        const int32_t r = bvh_build(ts, boxes, idx, mid, hi, first_global, pad, level + 1);
+        ftd::BspNode& nd = out.nodes[(size_t)node];
+        for (int a = 0; a < 3; ++a) { nd.bmin[a] = b.lo[a] - pad; nd.bmax[a] = b.hi[a] + pad; }   // inflated: pruning can never drop a real hit
+        nd.left = l; nd.right = r; nd.axis = (uint32_t)axis;
+        return node;
+    }
+    int32_t bvh_for_leaf(const std::vector<Tri3>& ts, uint32_t first_global) {
+        if (ts.size() < 8) return INT32_MIN;
+        std::vector<Box> boxes(ts.size());
+        double extent = 0.0;
+        for (size_t i = 0; i < ts.size(); ++i) {
+            const P3 p[3] = {ts[i].a, ts[i].b, ts[i].c};
+            Box& b = boxes[i];
+            for (int a = 0; a < 3; ++a) { b.lo[a] = std::numeric_limits<double>::infinity(); b.hi[a] = -b.lo[a]; }
+            for (auto& q : p) {
+                const double v[3] = {q.x, q.y, q.z};
+                for (int a = 0; a < 3; ++a) { if (!(std::fabs(v[a]) < 1e300)) return INT32_MIN; if (v[a] < b.lo[a]) b.lo[a] = v[a]; if (v[a] > b.hi[a]) b.hi[a] = v[a]; if (std::fabs(v[a]) > extent) extent = std::fabs(v[a]); }
+            }
+        }
+        std::vector<uint32_t> idx(ts.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
+        return bvh_build(ts, boxes, idx, 0, ts.size(), first_global, 1e-7 * extent + 1e-300, 0);
     }
 
     // BspMesh.compile (BspMesh.fs:51-65); returns a child reference.
@@ -444,6 +510,13 @@ int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatSce
     int32_t root = (n_tris == 0) ? b.make_leaf(ts) : b.compile(depth, ts, 0);   // an empty mesh is an empty group
     if (b.failed) return FT_ERR_BUILD;
     mesh.root = root; mesh.n_source_tris = (uint32_t)n_tris; mesh.max_depth = b.max_depth;
+    mesh.bvh_root = INT32_MIN;
+    if (root < 0) {                                                             // top-level Leaf: add the exact BVH for closest / any-hit queries
+        const size_t n0 = out.nodes.size(), l0 = out.bsp_leaves.size(), t0 = out.tris.size() / 9;
+        mesh.bvh_root = b.bvh_for_leaf(ts, out.bsp_leaves[(size_t)~root].first_tri);
+        out.bvh_nodes += (int64_t)(out.nodes.size() - n0); out.bvh_leaves += (int64_t)(out.bsp_leaves.size() - l0); out.bvh_tris += (int64_t)(out.tris.size() / 9 - t0);
+        if (mesh.bvh_root >= 0 && (int32_t)b.bvh_depth + 1 > out.stack_capacity) out.stack_capacity = (int32_t)b.bvh_depth + 1;
+    }
     return FT_OK;
 }
 

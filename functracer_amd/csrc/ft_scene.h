@@ -35,10 +35,13 @@ struct FlatScene {
     std::vector<ftd::BspNode> nodes;
     std::vector<ftd::BspLeaf> bsp_leaves;
     std::vector<double> tris;         // 9 per triangle: v0, e1, e2
+    std::vector<uint32_t> tri_orig;   // 1 per triangle (see ft_flat.h)
     std::vector<ftd::CullRecord> culls;
     std::vector<double> mesh_bounds;  // 6 per mesh: model-space AABB of the source triangles (lo > hi when empty)
     int32_t csg_capacity = 0;         // per-lane hit-list entries needed (0 = scene has no CSG)
-    int32_t stack_capacity = 0;       // per-lane BSP stack entries needed (0 = no BSP branches)
+    int32_t stack_capacity = 0;       // per-lane BSP / BVH stack entries needed (0 = no trees)
+    int32_t bsp_stack_capacity = 0;   // the part of it the reference-shaped BSP trees need
+    int64_t bvh_nodes = 0, bvh_leaves = 0, bvh_tris = 0;   // device-side BVH additions (not part of BspMesh.compile)
     bool any_reflective = false;
     bool any_texture = false;
     bool mesh_under_csg = false;

@@ -229,3 +229,27 @@ def test_quantise_matches_oracle(hip):
     rng = np.random.default_rng(1)
     rgb = rng.uniform(-0.5, 1.5, size=(1000, 3))
     assert np.array_equal(ft.quantise_rgba8(rgb), O.quantise_rgba8(rgb))
+
+
+def test_mesh_tie_break_follows_list_order(hip):
+    """Equal-t hits: closest keeps the earliest triangle of the list (stable sort, Scene.fs:114-116).
+    Coincident triangle pairs with opposite winding and exactly representable coordinates give exactly
+    equal t, so the winner shows in the sign of the normal.  16 triangles => the device-side BVH is used."""
+    rng = np.random.default_rng(12)
+    tris = []
+    for k in range(8):
+        x0, y0 = float(4 * k), float(rng.integers(-3, 3))
+        a, b, c = [x0, y0, 0.0], [x0 + 2, y0, 0.0], [x0, y0 + 2, 0.0]
+        pair = [a + b + c, a + c + b]                    # normals +Z and -Z
+        if k % 2:
+            pair.reverse()
+        tris += pair
+    tris = np.array(tris)
+    orc = O.Oracle()
+    for b_ in (orc, hip):
+        b_.clear(); b_.set_objects(b_.group([b_.bsp_mesh(0, tris)])); b_.commit()
+    o = np.array([[4.0 * k + 0.5, tris[2 * k][1] + 0.5, -4.0] for k in range(8)])
+    d = np.tile([0.0, 0.0, 2.0], (8, 1))
+    got, want = hip.closest(o, d), orc.closest(o, d)
+    assert want[0].all() and np.array_equal(want[3][:, 2], [1.0 if k % 2 == 0 else -1.0 for k in range(8)])
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
