@@ -45,7 +45,10 @@ struct ft_context {
     int64_t ray_capacity = 0;
     std::vector<hipEvent_t> events;
     size_t events_used = 0;
-    std::vector<uint32_t> last_pixels;   // tile pixel ids of the last render (empty = whole frame)
+    // pixel list of the last render, cached across calls with the same resolution and tiles
+    std::vector<uint32_t> pixels;
+    std::vector<ft_rect> pixel_rects;
+    bool pixels_whole = false;
     int64_t last_n_pix = 0;
     int32_t last_res_h = 0, last_res_v = 0;
     double k_ms[4] = {0, 0, 0, 0};
@@ -317,12 +320,12 @@ int32_t ft_fetch_frame(ft_context* c, double* out_rgb) {
     if (c->last_n_pix <= 0) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
     FT_HIP(c, hipSetDevice(c->device));
     const int64_t n = c->last_n_pix;
-    if (c->last_pixels.empty()) {
-        FT_HIP(c, hipMemcpy(out_rgb, c->d_out.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (c->pixels_whole) {                                         // k_blend wrote the frame in place
+        FT_HIP(c, hipMemcpy(out_rgb, c->d_out.p, (size_t)c->last_res_h * c->last_res_v * 24, hipMemcpyDeviceToHost));
     } else {
         std::vector<double> packed((size_t)n * 3);
         FT_HIP(c, hipMemcpy(packed.data(), c->d_out.p, packed.size() * 8, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; ++i) std::memcpy(out_rgb + 3 * (size_t)c->last_pixels[(size_t)i], &packed[3 * (size_t)i], 24);
+        for (int64_t i = 0; i < n; ++i) std::memcpy(out_rgb + 3 * (size_t)c->pixels[(size_t)i], &packed[3 * (size_t)i], 24);
     }
     return FT_OK;
 }
@@ -340,27 +343,48 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
     const auto wall0 = std::chrono::steady_clock::now();
     FT_HIP(c, hipSetDevice(c->device));
 
-    // pixel list (y-major, x: Image.fs:104) restricted to the tiles
-    std::vector<uint32_t> pixels;
+    // Pixel list restricted to the tiles.  The reference enumerates pixels y-major, x (Image.fs:104); samples are
+    // independent, so the device is free to walk them in any order: rects whose sides are multiples of 8 are
+    // walked in 8x8 pixel blocks, which makes the 64 lanes of a wavefront a compact bundle of rays.
     const bool whole = tiles == nullptr;
-    int64_t n_pix_total = (int64_t)res_h * res_v;
-    if (!whole) {
-        for (int k = 0; k < n_tiles; ++k)
-            for (int y = tiles[k].y0; y < tiles[k].y0 + tiles[k].h; ++y)
-                for (int x = tiles[k].x0; x < tiles[k].x0 + tiles[k].w; ++x)
-                    if (x >= 0 && x < res_h && y >= 0 && y < res_v) pixels.push_back((uint32_t)(y * res_h + x));
-        n_pix_total = (int64_t)pixels.size();
+    std::vector<ft_rect> rects;
+    if (whole) rects.push_back(ft_rect{0, 0, res_h, res_v});
+    else for (int k = 0; k < n_tiles; ++k) {
+        ft_rect r = tiles[k];
+        if (r.x0 < 0) { r.w += r.x0; r.x0 = 0; }
+        if (r.y0 < 0) { r.h += r.y0; r.y0 = 0; }
+        if (r.x0 + r.w > res_h) r.w = res_h - r.x0;
+        if (r.y0 + r.h > res_v) r.h = res_v - r.y0;
+        if (r.w > 0 && r.h > 0) rects.push_back(r);
     }
+    const bool same_list = c->last_n_pix > 0 && c->last_res_h == res_h && c->last_res_v == res_v && c->pixels_whole == whole &&
+                           c->pixel_rects.size() == rects.size() && (rects.empty() || std::memcmp(c->pixel_rects.data(), rects.data(), rects.size() * sizeof(ft_rect)) == 0);
+    if (!same_list) {
+        std::vector<uint32_t>& px = c->pixels;
+        px.clear();
+        for (const ft_rect& r : rects) {
+            if (r.w % 8 == 0 && r.h % 8 == 0) {
+                for (int ty = 0; ty < r.h; ty += 8) for (int tx = 0; tx < r.w; tx += 8)
+                    for (int iy = 0; iy < 8; ++iy) for (int ix = 0; ix < 8; ++ix) px.push_back((uint32_t)((r.y0 + ty + iy) * res_h + r.x0 + tx + ix));
+            } else {
+                for (int y = r.y0; y < r.y0 + r.h; ++y) for (int x = r.x0; x < r.x0 + r.w; ++x) px.push_back((uint32_t)(y * res_h + x));
+            }
+        }
+        c->pixel_rects = rects; c->pixels_whole = whole; c->last_n_pix = 0;
+    }
+    const std::vector<uint32_t>& pixels = c->pixels;
+    const int64_t n_pix_total = (int64_t)pixels.size();
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (n_pix_total == 0) return FT_OK;
 
     int32_t rc;
-    const int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, c->chunk_samples / spp));
+    int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, c->chunk_samples / spp));
+    if (pix_per_chunk > 64) pix_per_chunk -= pix_per_chunk % 64;      // keep 8x8 blocks (= wavefronts) whole
     const int64_t cap = pix_per_chunk * spp;
     if (cap > 0x7FFFFFFFll) { c->err = "chunk too large"; return FT_ERR_INVALID; }
     if ((rc = ensure_frame_buffers(c, cap)) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_out, (size_t)n_pix_total * 24)) != FT_OK) return rc;
-    if (!whole) { if ((rc = upload(c, c->d_pixels, pixels)) != FT_OK) return rc; }
+    if ((rc = ensure(c, c->d_out, (size_t)(whole ? (int64_t)res_h * res_v : n_pix_total) * 24)) != FT_OK) return rc;
+    if (!same_list) { if ((rc = upload(c, c->d_pixels, pixels)) != FT_OK) return rc; }
     std::vector<double> jit(jitter_xy, jitter_xy + 2 * (size_t)spp);
     if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
     FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
@@ -394,14 +418,15 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
         const uint32_t n_pix = (uint32_t)std::min<int64_t>(pix_per_chunk, n_pix_total - p0);
         const uint32_t n_samples = n_pix * (uint32_t)spp;
         FT_HIP(c, hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream));
-        timed(0, [&] { ftk::launch_generate(Lg, dcam, whole ? nullptr : c->d_pixels.as<uint32_t>(), (uint32_t)p0, n_pix, spp, c->d_jitter.as<double>(), rb[0], c->d_acc.as<double>(), cc); });
+        timed(0, [&] { ftk::launch_generate(Lg, dcam, c->d_pixels.as<uint32_t>(), (uint32_t)p0, n_pix, spp, c->d_jitter.as<double>(), rb[0], c->d_acc.as<double>(), cc); });
         ++n_launches;
         for (int b = 0; b <= last_bounce; ++b) {
             timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), b, cc, rcount); });
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
             n_launches += 2;
         }
-        timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, c->d_out.as<double>() + 3 * p0); });
+        timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, whole ? c->d_pixels.as<uint32_t>() + p0 : nullptr,
+                                             whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * p0); });
         ++n_launches;
     }
     if (ev1) (void)hipEventRecord(ev1, c->stream);
@@ -410,7 +435,6 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
 
     ftk::RenderCounters hrc{};
     FT_HIP(c, hipMemcpy(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost));
-    c->last_pixels = whole ? std::vector<uint32_t>() : pixels;
     c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v;
     if (out_rgb) { int32_t frc = ft_fetch_frame(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
     for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }

@@ -69,7 +69,8 @@ void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits
 void launch_shade(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
                   double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
-void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, double* out_rgb /* packed n_pix x 3 */);
+// out_index == nullptr: pixel p is written at out_rgb + 3p (packed); else at out_rgb + 3*out_index[p] (in place in the frame).
+void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb);
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,
                           int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc);

@@ -435,10 +435,72 @@ FT_DEV void mesh_bvh_query(const Scene& S, int32_t bvh_root, const Ray& r, Query
     if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
 }
 
+// The same query for a COHERENT wavefront (primary rays of one 8x8 pixel block and their shadow rays):
+// the 64 rays walk the BVH together.  The node stack and the current node are wave-uniform (the stack lives
+// in the lanes of one VGPR: lane i holds entry i, popped with v_readlane), node and triangle data come through scalar loads,
+// and there is no per-lane control flow: a node is entered if ANY live lane's slab test passes.  Lanes that
+// would have pruned a node on their own only run tests that cannot produce a usable hit for them (a
+// triangle lies inside its boxes), so the per-ray result equals mesh_bvh_query's.
+template <bool ANY>
+FT_DEV void mesh_bvh_packet(const Scene& S, int32_t bvh_root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit) {
+    bool alive = q.active && !(ANY && q.blocked);
+    if (!__any(alive)) return;
+    const double ivx = 1.0 / r.dx, ivy = 1.0 / r.dy, ivz = 1.0 / r.dz;
+    double bound = ANY ? q.max_dist : q.best_t;
+    uint32_t best_tri = 0xFFFFFFFFu;
+    bool found = false;
+    int stack_lanes = 0;                                           // lane i holds stack entry i (depth <= 64)
+    int sp = 0;
+    int cur = bvh_root;
+    for (;;) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        if (cur >= 0) {
+            cdp nd = S.nodes + 8ull * (uint32_t)cur;
+            double t0 = (nd[0] - r.ox) * ivx, t1 = (nd[3] - r.ox) * ivx;
+            double tmin = fmin(t0, t1), tmax = fmax(t0, t1);
+            t0 = (nd[1] - r.oy) * ivy; t1 = (nd[4] - r.oy) * ivy;
+            tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+            t0 = (nd[2] - r.oz) * ivz; t1 = (nd[5] - r.oz) * ivz;
+            tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+            const bool enter = alive && tmax >= fmax(tmin, 0.0) && tmin <= bound;
+            const unsigned long long m = __ballot(enter);
+            if (m) {
+                cip ch = reinterpret_cast<cip>(nd + 6);
+                const uint32_t axis = reinterpret_cast<cup>(nd + 7)[0];
+                const double da = axis == 0 ? r.dx : axis == 1 ? r.dy : r.dz;
+                const unsigned long long fwd = __ballot(enter && da >= 0.0);
+                const bool left_first = 2 * __popcll(fwd) >= __popcll(m);     // majority vote on the near child
+                const int near = left_first ? ch[0] : ch[1], far = left_first ? ch[1] : ch[0];
+                stack_lanes = ((int)lane_id() == sp) ? far : stack_lanes;   // "writelane": one compare + select
+                ++sp;
+                cur = near;
+                continue;
+            }
+        } else {
+            const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
+            for (uint32_t k = 0; k < count; ++k) {                 // wave-uniform: scalar loads
+                double t;
+                if (alive && tri_hit(S.tris + 9ull * (first + k), r, t)) {
+                    if (ANY) { if (t < bound) { q.blocked = true; alive = false; } }
+                    else {
+                        const uint32_t orig = S.tri_orig[first + k];
+                        if (t < bound || (found && t == bound && orig < best_tri)) { bound = t; best_tri = orig; found = true; }
+                    }
+                }
+            }
+            if (ANY) { if (!__any(alive)) break; }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = __builtin_amdgcn_readlane(stack_lanes, sp);
+    }
+    if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
 template <bool ANY>
-FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow) {
+FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow, bool coherent = false) {
     HitList L;
     L.init(lds, S.csg_cap);
     int32_t* stack = reinterpret_cast<int32_t*>(lds + 4 * S.csg_cap * kBlock) + threadIdx.x;
@@ -456,7 +518,8 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                     if (bvh >= 0) {
                         Ray rm;
                         to_model(S.leaves + 16ull * arg, (H.flags & LF_XFORM) != 0, r, rm);
-                        mesh_bvh_query<ANY>(S, bvh, rm, q, arg, lit, stack);
+                        if (coherent) mesh_bvh_packet<ANY>(S, bvh, rm, q, arg, lit);
+                        else mesh_bvh_query<ANY>(S, bvh, rm, q, arg, lit, stack);
                         break;
                     }
                 }
@@ -565,9 +628,18 @@ FT_DEV Surface surface_at(const Scene& S, const Ray& rw, double t, uint32_t id0,
 }
 
 // Wave-cooperative grab of the next 64-item batch from a persistent work cursor.
-FT_DEV uint32_t grab_batch(uint32_t* cursor) {
+// Work distribution.  A persistent wave pulls a UNIT of up to 16 consecutive 64-ray batches with one
+// returning atomic: a single device-scope counter word saturates at about 88 dequeues per microsecond on
+// this chip (MI355X_MICROARCH.md, row "dequeue"), which with one atomic per 64 rays capped every kernel at
+// ~5.6 Grays/s.  The unit shrinks with the launch size so that small launches still spread over all waves.
+FT_DEV uint32_t unit_batches_for(uint32_t n) {
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    uint32_t u = n / (64u * waves * 4u);                            // aim at >= 4 units per wave
+    return u < 1u ? 1u : (u > 16u ? 16u : u);
+}
+FT_DEV uint32_t grab_unit(uint32_t* cursor, uint32_t rays) {
     uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(cursor, 64u);
+    if (lane_id() == 0) base = atomicAdd(cursor, rays);
     return __builtin_amdgcn_readfirstlane(base);
 }
 
@@ -602,31 +674,45 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, RayBuf rays, Hi
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
     const uint32_t n = cc->n_rays[bounce];
+    const uint32_t unit = unit_batches_for(n);
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
     for (;;) {
-        const uint32_t base = grab_batch(&cc->work_trace[bounce]);
-        if (base >= n) break;
-        const uint32_t i = base + lane_id();
-        Query<false> q;
-        q.active = i < n; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
-        Ray r{0, 0, 0, 0, 0, 0};
-        if (q.active) {
-            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
-            r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
+        const uint32_t ubase = grab_unit(&cc->work_trace[bounce], unit * 64u);
+        if (ubase >= n) break;
+        uint32_t mask_lo = 0, mask_hi = 0, unit_hits = 0;          // lane b keeps the hit mask of batch b of this unit
+        for (uint32_t b = 0; b < unit; ++b) {
+            const uint32_t base = ubase + b * 64u;
+            if (base >= n) break;
+            const uint32_t i = base + lane_id();
+            Query<false> q;
+            q.active = i < n; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
+            Ray r{0, 0, 0, 0, 0, 0};
+            if (q.active) {
+                r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
+                r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
+            }
+            bool overflow;
+            trace<false>(S, r, q, lds, overflow, bounce == 0);    // primary rays of one pixel block walk meshes as a packet
+            const bool hit = q.active && q.id0 != ID_MISS;
+            if (q.active) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }
+            const unsigned long long m = __ballot(hit);
+            if (lane_id() == b) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); }
+            unit_hits += (uint32_t)__popcll(m);
+            n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
         }
-        bool overflow;
-        trace<false>(S, r, q, lds, overflow);
-        const bool hit = q.active && q.id0 != ID_MISS;
-        if (q.active) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }
-        // wave-ballot / prefix-sum compaction of the rays that hit
-        const unsigned long long m = __ballot(hit);
-        const uint32_t cnt = (uint32_t)__popcll(m);
+        // wave-ballot / prefix-sum compaction of the rays that hit: one reservation per unit
         uint32_t dst = 0;
-        if (lane_id() == 0 && cnt) dst = atomicAdd(&cc->n_hits[bounce], cnt);
+        if (lane_id() == 0 && unit_hits) dst = atomicAdd(&cc->n_hits[bounce], unit_hits);
         dst = __builtin_amdgcn_readfirstlane(dst);
-        if (hit) hit_list[dst + lanes_below(m)] = i;
-        n_hit_wave += cnt;
-        n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
+        if (unit_hits) {
+            for (uint32_t b = 0; b < unit; ++b) {
+                const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_lo, (int)b) |
+                                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_hi, (int)b) << 32);
+                if ((m >> lane_id()) & 1ull) hit_list[dst + lanes_below(m)] = ubase + b * 64u + lane_id();
+                dst += (uint32_t)__popcll(m);
+            }
+        }
+        n_hit_wave += unit_hits;
     }
     if (bounce == 0) wave_add(&rc->hits_primary, n_hit_wave);
     wave_add(&rc->csg_overflow, n_ovf_wave);
@@ -640,9 +726,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, RayBuf rays, HitB
     const uint32_t n = cc->n_hits[bounce];
     const int n_lights = S.n_lights;
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
-    for (;;) {
-        const uint32_t base = grab_batch(&cc->work_shade[bounce]);
-        if (base >= n) break;
+    const uint32_t unit = unit_batches_for(n);
+    for (uint32_t ub = 0, ubase = 0;; ++ub) {
+        if (ub % unit == 0) ubase = grab_unit(&cc->work_shade[bounce], unit * 64u);
+        const uint32_t base = ubase + (ub % unit) * 64u;
+        if (base >= n) { if (ub % unit == 0) break; ub += unit - 1 - (ub % unit); continue; }
         const uint32_t j = base + lane_id();
         const bool active = j < n;
         Ray r{0, 0, 0, 0, 0, 0};
@@ -683,7 +771,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, RayBuf rays, HitB
                 ld = {lt.v[0], lt.v[1], lt.v[2]};
             }
             bool overflow = false;
-            if (__any(lit)) trace<true>(S, sr, q, lds, overflow);
+            if (__any(lit)) trace<true>(S, sr, q, lds, overflow, bounce == 0);
             n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
             n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && lit));
             if (lit) {
@@ -740,14 +828,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, RayBuf rays, HitB
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* __restrict__ out_index, double* __restrict__ out) {
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
         double r = 0.0, g = 0.0, b = 0.0;                          // Array.average: sum from Zero in sample order, then DivideByInt
         for (int s = 0; s < spp; ++s) {
             const size_t i = (size_t)s * n_pix + p;
             r += acc[i]; g += acc[(size_t)acc_stride + i]; b += acc[2 * (size_t)acc_stride + i];
         }
-        out[3 * (size_t)p] = r / (double)spp; out[3 * (size_t)p + 1] = g / (double)spp; out[3 * (size_t)p + 2] = b / (double)spp;
+        const size_t o = out_index ? out_index[p] : p;
+        out[3 * o] = r / (double)spp; out[3 * o + 1] = g / (double)spp; out[3 * o + 2] = b / (double)spp;
     }
 }
 
@@ -812,8 +901,8 @@ void launch_shade(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, 
                   uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
     hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
 }
-void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, double* out_rgb) {
-    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, n_pix, spp, out_rgb);
+void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
+    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, n_pix, spp, out_index, out_rgb);
 }
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n, int32_t* hit, double* t,
                           double* p, double* nrm, double* colour, RenderCounters* rc) {
