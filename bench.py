@@ -82,7 +82,7 @@ def main():
     t0 = time.perf_counter()
     rays = 0
     kernel_ms = trace_ms = 0.0
-    k_times = {"generate": 0.0, "closest": 0.0, "shade": 0.0, "blend": 0.0}
+    k_times = {"clear": 0.0, "closest": 0.0, "shade": 0.0, "blend": 0.0}
     k_launch = dict.fromkeys(k_times, 0)
     st = None
     for _ in range(args.steps):

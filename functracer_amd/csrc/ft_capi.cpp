@@ -418,11 +418,12 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
         const uint32_t n_pix = (uint32_t)std::min<int64_t>(pix_per_chunk, n_pix_total - p0);
         const uint32_t n_samples = n_pix * (uint32_t)spp;
         FT_HIP(c, hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream));
-        timed(0, [&] { ftk::launch_generate(Lg, dcam, c->d_pixels.as<uint32_t>(), (uint32_t)p0, n_pix, spp, c->d_jitter.as<double>(), rb[0], c->d_acc.as<double>(), cc); });
+        const ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), (uint32_t)p0, n_pix, spp};
+        timed(0, [&] { (void)hipMemsetAsync(c->d_acc.p, 0, (size_t)n_samples * 24, c->stream); });   // accumulators start at Colour.Zero
         ++n_launches;
         for (int b = 0; b <= last_bounce; ++b) {
-            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), b, cc, rcount); });
-            timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
+            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), b, cc, rcount); });
+            timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
             n_launches += 2;
         }
         timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, whole ? c->d_pixels.as<uint32_t>() + p0 : nullptr,

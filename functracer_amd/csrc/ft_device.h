@@ -59,14 +59,19 @@ struct Launch {
     size_t lds_bytes;
 };
 
-// K1: primary rays for chunk pixels [0,n_pix) x spp, slot = s*n_pix + pix; zeroes the accumulators.
-void launch_generate(const Launch& L, const Camera& cam, const uint32_t* pixel_ids, uint32_t pix_base, uint32_t n_pix,
-                     int32_t spp, const double* jitter, RayBuf rays, double* acc, ChunkCounters* cc);
+// Everything bounce 0 needs to regenerate a primary ray from its sample index i = s*n_pix + pixel.
+struct Primary {
+    Camera cam;
+    const uint32_t* pixel_ids;     // pixel id (y*res_h + x) of list entry pix_base + pixel
+    const double* jitter;          // spp x 2, the ONE pattern shared by every pixel (Image.fs:105)
+    uint32_t pix_base, n_pix;
+    int32_t spp;
+};
 // K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.
-void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce,
+void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce,
                     ChunkCounters* cc, RenderCounters* rc);
 // K3: shading + shadow rays + accumulation for the compacted hits of bounce k; emits bounce k+1 rays.
-void launch_shade(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
+void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
                   double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
 // out_index == nullptr: pixel p is written at out_rgb + 3p (packed); else at out_rgb + 3*out_index[p] (in place in the frame).

@@ -1,7 +1,7 @@
 // ft_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the FuncTracer render loop.
 //
 // Pipeline per chunk of samples (DESIGN.md §"Kernels"):
-//   k_generate  primary rays        Image.fs:83-89, 100-110
+//   (primary rays are generated inside bounce 0 of the two kernels below: Image.fs:83-89, 100-110)
 //   k_closest   closest hit         Scene.fs:112-118 over the flattened Scene.intersect (Scene.fs:67-104)
 //   k_shade     Phong + shadow rays + reflection spawn   Shading.fs:24-139
 //   k_blend     per-pixel mean      Image.fs:112-116
@@ -649,31 +649,24 @@ FT_DEV void wave_add(unsigned long long* dst, unsigned long long v_per_lane_flag
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_generate(Camera cam, const uint32_t* __restrict__ pixel_ids, uint32_t pix_base, uint32_t n_pix,
-                                                      int32_t spp, const double* __restrict__ jitter, RayBuf rays, double* __restrict__ acc, ChunkCounters* cc) {
-    const uint32_t n = n_pix * (uint32_t)spp;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const uint32_t s = i / n_pix, pl = i - s * n_pix;          // slot = s*n_pix + pixel: adjacent lanes = adjacent pixels
-        const uint32_t pid = pixel_ids ? pixel_ids[pix_base + pl] : pix_base + pl;
-        const uint32_t py = pid / (uint32_t)cam.res_h, px = pid - py * (uint32_t)cam.res_h;
-        // ImagePlane.rayThroughPixel (Image.fs:83-89)
-        const double centre_x = cam.tlx + (double)px * cam.pw, centre_y = cam.tly - (double)py * cam.ph;
-        const double jx = centre_x + jitter[2 * s] * cam.pw, jy = centre_y + jitter[2 * s + 1] * cam.ph;
-        rays.ox[i] = cam.o[0]; rays.oy[i] = cam.o[1]; rays.oz[i] = cam.o[2];
-        rays.dx[i] = (cam.k[0] + jx * cam.i[0]) + jy * cam.j[0];
-        rays.dy[i] = (cam.k[1] + jx * cam.i[1]) + jy * cam.j[1];
-        rays.dz[i] = (cam.k[2] + jx * cam.i[2]) + jy * cam.j[2];
-        rays.w[i] = 1.0; rays.slot[i] = i;
-        acc[i] = 0.0; acc[(size_t)n + i] = 0.0; acc[2 * (size_t)n + i] = 0.0;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) cc->n_rays[0] = n;
+// Primary rays are never stored: bounce 0 of k_closest / k_shade regenerates them from the sample index
+// (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
+// 64 pixels of one 8x8 block for one jitter offset).
+FT_DEV Ray primary_ray(const Primary& g, uint32_t i) {
+    const uint32_t s = i / g.n_pix, pl = i - s * g.n_pix;
+    const uint32_t pid = g.pixel_ids[g.pix_base + pl];
+    const uint32_t py = pid / (uint32_t)g.cam.res_h, px = pid - py * (uint32_t)g.cam.res_h;
+    const double centre_x = g.cam.tlx + (double)px * g.cam.pw, centre_y = g.cam.tly - (double)py * g.cam.ph;
+    const double jx = centre_x + g.jitter[2 * s] * g.cam.pw, jy = centre_y + g.jitter[2 * s + 1] * g.cam.ph;
+    return {g.cam.o[0], g.cam.o[1], g.cam.o[2],
+            (g.cam.k[0] + jx * g.cam.i[0]) + jy * g.cam.j[0], (g.cam.k[1] + jx * g.cam.i[1]) + jy * g.cam.j[1], (g.cam.k[2] + jx * g.cam.i[2]) + jy * g.cam.j[2]};
 }
 
-__global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
+__global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
                                                      ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
-    const uint32_t n = cc->n_rays[bounce];
+    const uint32_t n = bounce == 0 ? gen.n_pix * (uint32_t)gen.spp : cc->n_rays[bounce];
     const uint32_t unit = unit_batches_for(n);
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
     for (;;) {
@@ -688,7 +681,8 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, RayBuf rays, Hi
             q.active = i < n; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
             Ray r{0, 0, 0, 0, 0, 0};
             if (q.active) {
-                r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
+                if (bounce == 0) r = primary_ray(gen, i);
+                else r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
                 r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
             }
             bool overflow;
@@ -718,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, RayBuf rays, Hi
     wave_add(&rc->csg_overflow, n_ovf_wave);
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
                                                    double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
                                                    ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -737,8 +731,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, RayBuf rays, HitB
         double w = 0.0, t = 0.0; uint32_t slot = 0, id0 = 0, id1 = 0;
         if (active) {
             const uint32_t i = hit_list[j];
-            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
-            w = rays.w[i]; slot = rays.slot[i];
+            if (bounce == 0) { r = primary_ray(gen, i); w = 1.0; slot = i; }
+            else { r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i]; }
             t = hits.t[i]; id0 = hits.id0[i]; id1 = hits.id1[i];
         }
         // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
@@ -890,16 +884,12 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
 // ============================================================================================ launchers
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
-void launch_generate(const Launch& L, const Camera& cam, const uint32_t* pixel_ids, uint32_t pix_base, uint32_t n_pix, int32_t spp,
-                     const double* jitter, RayBuf rays, double* acc, ChunkCounters* cc) {
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_pix * (uint32_t)spp, L.grid * 4)), dim3(kBlock), 0, L.stream, cam, pixel_ids, pix_base, n_pix, spp, jitter, rays, acc, cc);
+void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, ChunkCounters* cc, RenderCounters* rc) {
+    hipLaunchKernelGGL(k_closest, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, bounce, cc, rc);
 }
-void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, ChunkCounters* cc, RenderCounters* rc) {
-    hipLaunchKernelGGL(k_closest, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, rays, hits, hit_list, bounce, cc, rc);
-}
-void launch_shade(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
+void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
                   uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
-    hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
+    hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
 }
 void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, n_pix, spp, out_index, out_rgb);

@@ -186,7 +186,8 @@ int32_t ft_create_host_only(ft_context** out);
 int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[8]);
 int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9],
                        double above[18], int32_t* n_above, double below[18], int32_t* n_below);
-/* HIP-event time per kernel over the last ft_render: index 0 generate, 1 closest, 2 shade, 3 blend. */
+/* HIP-event time per stage over the last ft_render: index 0 accumulator clear (primary rays are generated inside bounce 0),
+ * 1 closest, 2 shade, 3 blend. */
 int32_t ft_get_kernel_times(ft_context* ctx, double ms[4], int32_t launches[4]);
 
 /* Image.write's toByte (Image.fs:36): clamp to [0,1], *255, truncate; alpha = 255. */
