@@ -16,7 +16,7 @@
 
 namespace ftk {
 int occupancy_blocks_closest(size_t lds_bytes);
-int occupancy_blocks_shade(size_t lds_bytes);
+int occupancy_blocks_shade(size_t lds_bytes, int variant);
 }
 
 struct DeviceBuf {
@@ -38,7 +38,7 @@ struct ft_context {
     int64_t chunk_samples = 8ll << 20;
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
@@ -172,7 +172,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -292,6 +292,7 @@ int32_t ft_scene_commit(ft_context* c) {
     if ((rc = upload(c, c->d_m2w, f.m2w)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_materials, f.materials)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_lights, f.lights)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_textures, f.textures)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_program, f.program)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_meshes, f.meshes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_nodes, f.nodes)) != FT_OK) return rc;
@@ -304,7 +305,7 @@ int32_t ft_scene_commit(ft_context* c) {
     FT_HIP(c, hipStreamSynchronize(c->stream));
     ftk::DevScene& S = c->dev_scene;
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
-    S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>();
+    S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>(); S.textures = c->d_textures.as<ftd::Texture>();
     S.program = c->d_program.as<uint32_t>(); S.meshes = c->d_meshes.as<ftd::Mesh>();
     S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>(); S.tri_orig = c->d_tri_orig.as<uint32_t>();
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
@@ -391,9 +392,11 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
 
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
-    ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds), lds};
-    ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds), lds};
-    ftk::Launch Lg{c->stream, c->n_cu * 8, 0};
+    int variant = 0;
+    for (auto& m : c->flat.materials) { if (m.roughness != 0.0) variant |= 1; if (m.texture >= 0) variant |= 2; }
+    ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds), lds, 0};
+    ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds, variant), lds, variant};
+    ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
     const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
     ftk::HitBuf hb{c->d_hits.as<double>(), reinterpret_cast<uint32_t*>(c->d_hits.as<double>() + c->ray_capacity),
@@ -485,7 +488,7 @@ int32_t ft_debug_closest(ft_context* c, const double* origins, const double* dir
     double* dp = dt + N; double* dn = dp + 3 * N; double* dc = dn + 3 * N;
     int32_t* dh = reinterpret_cast<int32_t*>(dc + 3 * N);
     const size_t lds = lds_bytes_for(c->flat);
-    ftk::Launch L{c->stream, c->n_cu * 4, lds};
+    ftk::Launch L{c->stream, c->n_cu * 4, lds, 0};
     ftk::launch_debug_closest(L, c->dev_scene, din, din + 3 * N, (uint32_t)n, dh, dt, dp, dn, dc, c->d_rc.as<ftk::RenderCounters>());
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipMemcpyAsync(t, dt, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -516,7 +519,7 @@ int32_t ft_debug_blocked(ft_context* c, const double* origins, const double* dir
     FT_HIP(c, hipMemcpyAsync(din + 6 * N, max_dist, N * 8, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
     const size_t lds = lds_bytes_for(c->flat);
-    ftk::Launch L{c->stream, c->n_cu * 4, lds};
+    ftk::Launch L{c->stream, c->n_cu * 4, lds, 0};
     ftk::launch_debug_blocked(L, c->dev_scene, din, din + 3 * N, din + 6 * N, (uint32_t)n, c->d_dbg_out.as<int32_t>(), c->d_rc.as<ftk::RenderCounters>());
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipMemcpyAsync(blocked, c->d_dbg_out.p, N * 4, hipMemcpyDeviceToHost, c->stream));

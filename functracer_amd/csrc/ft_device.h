@@ -17,6 +17,7 @@ struct DevScene {
     const double* m2w;             // n_leaves x 12
     const ftd::Material* materials;
     const ftd::Light* lights;
+    const ftd::Texture* textures;
     const uint32_t* program;
     const ftd::Mesh* meshes;
     const ftd::BspNode* nodes;
@@ -57,6 +58,7 @@ struct Launch {
     hipStream_t stream;
     int grid;                      // persistent grid size (workgroups)
     size_t lds_bytes;
+    int variant;                   // k_shade: bit 0 = Oren-Nayar compiled in, bit 1 = textures compiled in
 };
 
 // Everything bounce 0 needs to regenerate a primary ray from its sample index i = s*n_pix + pixel.

@@ -54,6 +54,16 @@ struct Material {          // Ray.fs:4-10; 64 bytes
     uint32_t pad;
 };
 
+// Scene.Texture (Scene.fs:47-53): a Grid under at most 5 uv functions, outermost (applied first) first.
+// 24 doubles.  op kind 0 = Texture.scale (u/a, v/b) (Texture.fs:14-16); kind 1 = Texture.rotate with
+// a = cos, b = sin of the angle (Texture.fs:18-22).
+struct Texture {
+    double c1[3], c2[3];
+    double n_ops;
+    double ops[5][3];
+    double pad[2];
+};
+
 enum LightKind : uint32_t { LT_DIRECTIONAL = 0, LT_SOFT = 1, LT_POINT = 2 };
 struct Light {             // Light.fs:7-14; 96 bytes
     double v[3];           // normalised direction | position

@@ -51,6 +51,7 @@ struct Scene {
     cdp m2w;          // 12 per leaf
     cdp materials;    // 8 doubles per ftd::Material
     cdp lights;       // 12 doubles per ftd::Light
+    cdp textures;     // 24 doubles per ftd::Texture
     cup program;
     cip meshes;       // 4 words per ftd::Mesh
     cdp nodes;        // 8 doubles per ftd::BspNode
@@ -60,23 +61,24 @@ struct Scene {
     cup tri_orig;     // 1 per triangle
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
 };
-static_assert(sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
+static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
 FT_DEV Scene scene_view(const DevScene& g) {
     Scene s;
     s.leaves = to_const_as(g.leaves); s.m2w = to_const_as(g.m2w);
     s.materials = to_const_as(reinterpret_cast<const double*>(g.materials)); s.lights = to_const_as(reinterpret_cast<const double*>(g.lights));
+    s.textures = to_const_as(reinterpret_cast<const double*>(g.textures));
     s.program = to_const_as(g.program); s.meshes = to_const_as(reinterpret_cast<const int32_t*>(g.meshes));
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig);
     s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
     return s;
 }
-struct MaterialV { double colour[3]; double roughness, reflectance, shineyness; uint32_t apply_lighting; };
+struct MaterialV { double colour[3]; double roughness, reflectance, shineyness; uint32_t apply_lighting; int32_t texture; uint32_t hue_rot; };
 FT_DEV MaterialV material_at(const Scene& S, uint32_t i) {
     cdp m = S.materials + 8ull * i;
     MaterialV v;
     v.colour[0] = m[0]; v.colour[1] = m[1]; v.colour[2] = m[2]; v.roughness = m[3]; v.reflectance = m[4]; v.shineyness = m[5];
-    v.apply_lighting = reinterpret_cast<cup>(m + 6)[0];
+    v.apply_lighting = reinterpret_cast<cup>(m + 6)[0]; v.texture = reinterpret_cast<cip>(m + 6)[1]; v.hue_rot = reinterpret_cast<cup>(m + 7)[0];
     return v;
 }
 
@@ -567,7 +569,7 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
 // ---------------------------------------------------------------------------------------------
 // Surface point, normal and material of a closest hit (recomputed from t + hit identity; the
 // reference computes them for every candidate hit, the values for the winner are the same).
-struct Surface { V3 p, n; uint32_t material; };
+struct Surface { V3 p, n; uint32_t material; double u, v; };   // (u,v) = TextureCoords of the hit (Ray.fs:20,26), filled when the material is textured
 
 FT_DEV void cylinder_side(const Ray& r, double t, V3& p, V3& n) {   // Cylinder.fs:14-17
     p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz};
@@ -575,6 +577,7 @@ FT_DEV void cylinder_side(const Ray& r, double t, V3& p, V3& n) {   // Cylinder.
     n = (dot3(nn.x, nn.y, nn.z, r.dx, r.dy, r.dz) < 0.0) ? nn : V3{-nn.x, -nn.y, -nn.z};
 }
 
+template <bool TEXTURED>
 FT_DEV Surface surface_at(const Scene& S, const Ray& rw, double t, uint32_t id0, uint32_t id1) {
     const uint32_t leaf = id0 & ID_LEAF_MASK, sub = (id0 >> ID_SUB_SHIFT) & ID_SUB_MASK;
     const LeafHead H = leaf_head(S, leaf);
@@ -583,11 +586,20 @@ FT_DEV Surface surface_at(const Scene& S, const Ray& rw, double t, uint32_t id0,
     Ray r;
     to_model(M, xform, rw, r);
     V3 p, n;
+    double tu = 0.0, tv = 0.0;                                     // newIntersection: uv = (0,0) (Ray.fs:29)
+    const bool textured = TEXTURED && reinterpret_cast<cip>(S.materials + 8ull * H.material + 6)[1] >= 0;
     switch (H.kind) {
-        case LK_SPHERE: p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = normalise(p); break;
-        case LK_PLANE: case LK_SQUARE: case LK_CIRCLE: p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = {0.0, 1.0, 0.0}; break;
+        case LK_SPHERE:
+            p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = normalise(p);
+            if (textured) { tu = 0.5 + atan2(n.z, n.x) / (2.0 * 3.14159265358979323846); tv = 0.5 - asin(n.y) / 3.14159265358979323846; }   // Sphere.setUV (Sphere.fs:6-10)
+            break;
+        case LK_PLANE: case LK_SQUARE: case LK_CIRCLE:
+            p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = {0.0, 1.0, 0.0}; tu = p.x; tv = p.z;   // Plane.setUV (Plane.fs:28-30)
+            break;
         case LK_CUBE: {
             const double qx = r.ox + 0.5, qy = r.oy + 0.5, qz = r.oz + 0.5;
+            const double hx = qx + t * r.dx, hy = qy + t * r.dy, hz = qz + t * r.dz;
+            tu = sub < 2 ? hx : sub < 4 ? hy : hx; tv = sub < 4 ? hz : hy;   // each face is a square: (x,z) of its own frame
             p = {(qx + t * r.dx) - 0.5, (qy + t * r.dy) - 0.5, (qz + t * r.dz) - 0.5};
             n = {sub == 2 ? -1.0 : sub == 3 ? 1.0 : 0.0, sub == 0 ? -1.0 : sub == 1 ? 1.0 : 0.0, sub == 4 ? -1.0 : sub == 5 ? 1.0 : 0.0};
             break;
@@ -603,8 +615,8 @@ FT_DEV Surface surface_at(const Scene& S, const Ray& rw, double t, uint32_t id0,
         case LK_CYLINDER: cylinder_side(r, t, p, n); break;
         case LK_SOLIDCYL: {
             if (sub >= 2) cylinder_side(r, t, p, n);
-            else if (sub == 0) { const double oyt = r.oy - 1.0; p = {r.ox + t * r.dx, (oyt + t * r.dy) + 1.0, r.oz + t * r.dz}; n = {0.0, 1.0, 0.0}; }
-            else { p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = {0.0, -1.0, 0.0}; }
+            else if (sub == 0) { const double oyt = r.oy - 1.0; p = {r.ox + t * r.dx, (oyt + t * r.dy) + 1.0, r.oz + t * r.dz}; n = {0.0, 1.0, 0.0}; tu = p.x; tv = p.z; }
+            else { p = {r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz}; n = {0.0, -1.0, 0.0}; tu = -p.x; tv = p.z; }
             break;
         }
         default: {                                                 // triangle (Triangle.fs:63-64)
@@ -624,10 +636,26 @@ FT_DEV Surface surface_at(const Scene& S, const Ray& rw, double t, uint32_t id0,
     }
     const bool flip = (((H.flags & LF_FLIP) != 0) != ((id0 & ID_FLIP) != 0));
     if (flip) n = {-n.x, -n.y, -n.z};
-    return {p, n, H.material};
+    return {p, n, H.material, tu, tv};
 }
 
 // Wave-cooperative grab of the next 64-item batch from a persistent work cursor.
+// Texture.grid under its uv functions (Textures/Texture.fs:8-29), then the hueShift rotations that follow it.
+FT_DEV void textured_colour(const Scene& S, const MaterialV& mat, double u, double v, double col[3]) {
+    cdp T = S.textures + 24ull * (uint32_t)mat.texture;
+    const int n_ops = (int)T[6];
+    for (int k = 0; k < n_ops; ++k) {
+        const double kind = T[7 + 3 * k], a = T[8 + 3 * k], b = T[9 + 3 * k];
+        if (kind == 0.0) { u = u / a; v = v / b; }
+        else { const double x = a * u + 0.0 * 0.0 + b * v, z = -b * u + 0.0 * 0.0 + a * v; u = x; v = z; }
+    }
+    const double ru = fabs(u - floor(u)), rv = fabs(v - floor(v));                 // Texture.repeat
+    const bool first = (ru < 0.5 && rv < 0.5) ? true : (ru < 0.5) ? false : (ru > 0.5 && rv > 0.5);
+    cdp c = first ? T : T + 3;
+    col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
+    for (uint32_t h = 0; h < mat.hue_rot; ++h) { const double r = col[0], g = col[1], b = col[2]; col[0] = b; col[1] = r; col[2] = g; }   // CommonTypes.fs:90
+}
+
 // Work distribution.  A persistent wave pulls a UNIT of up to 16 consecutive 64-ray batches with one
 // returning atomic: a single device-scope counter word saturates at about 88 dequeues per microsecond on
 // this chip (MI355X_MICROARCH.md, row "dequeue"), which with one atomic per 64 rays capped every kernel at
@@ -712,6 +740,9 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, Ra
     wave_add(&rc->csg_overflow, n_ovf_wave);
 }
 
+// ROUGH / TEXTURED select the variants with Oren-Nayar and grid textures compiled in: they need libm-heavy
+// code (acos, tan, atan2 ...) whose registers would otherwise halve the occupancy of every scene.
+template <bool ROUGH, bool TEXTURED>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
                                                    double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
                                                    ChunkCounters* cc, RenderCounters* rc) {
@@ -738,8 +769,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
         // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
         const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
         Surface sf{{0, 0, 0}, {0, 1, 0}, 0};
-        if (active) sf = surface_at(S, ro, t, id0, id1);
-        const MaterialV mat = material_at(S, sf.material);            // per-lane gather (64 B records, L1/L2 resident)
+        if (active) sf = surface_at<TEXTURED>(S, ro, t, id0, id1);
+        MaterialV mat = material_at(S, sf.material);                  // per-lane gather (64 B records, L1/L2 resident)
+        if (TEXTURED) { if (active && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }   // Ray.textureDiffuse (Ray.fs:57-59)
         const bool lit = active && mat.apply_lighting != 0;
         double cr = 0.0, cg = 0.0, cb = 0.0;                       // sum over fragments (Seq.sumBy shader, Shading.fs:139)
         // getLightsOnPoint (Shading.fs:109-117)
@@ -782,9 +814,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
                     if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
                 }
                 // reflectionShader is carried by the path weight (below); lambertianDiffuse (Shading.fs:65-70)
-                {
+                if (!ROUGH || mat.roughness == 0.0) {              // diffuseShader (Shading.fs:72-76)
                     const double di = dot3(-ld.x, -ld.y, -ld.z, sf.n.x, sf.n.y, sf.n.z);
                     fr = fr + di * (mat.colour[0] * lcr); fg = fg + di * (mat.colour[1] * lcg); fb = fb + di * (mat.colour[2] * lcb);
+                } else {                                           // roughDiffuse: Oren-Nayar (Shading.fs:50-63); the light colour is not used (sic)
+                    const double rough = mat.roughness * mat.roughness;
+                    const V3 nn = normalise(sf.n), nv = normalise(V3{-r.dx, -r.dy, -r.dz}), nl = normalise(V3{-ld.x, -ld.y, -ld.z});
+                    const double ray_angle = acos(dot3(nn.x, nn.y, nn.z, nv.x, nv.y, nv.z)), light_angle = acos(dot3(nn.x, nn.y, nn.z, nl.x, nl.y, nl.z));
+                    const double alpha = fs_max(ray_angle, light_angle), beta = fs_min(ray_angle, light_angle);
+                    const double A = 1.0 - 0.5 * rough / (rough + 0.33), B = 0.45 * rough / (rough + 0.09);
+                    const double kl = dot3(-ld.x, -ld.y, -ld.z, nn.x, nn.y, nn.z), kv = dot3(-r.dx, -r.dy, -r.dz, nn.x, nn.y, nn.z);
+                    const V3 tl = normalise(V3{-ld.x - kl * nn.x, -ld.y - kl * nn.y, -ld.z - kl * nn.z});   // perpendicularComponent (CommonTypes.fs:77-79)
+                    const V3 tr = normalise(V3{-r.dx - kv * nn.x, -r.dy - kv * nn.y, -r.dz - kv * nn.z});
+                    const double di = cos(light_angle) * (A + (B * fs_max(0.0, dot3(tl.x, tl.y, tl.z, tr.x, tr.y, tr.z)) * sin(alpha) * tan(beta)));
+                    fr = fr + di * mat.colour[0]; fg = fg + di * mat.colour[1]; fb = fb + di * mat.colour[2];
                 }
                 cr += fr; cg += fg; cb += fb;
             }
@@ -852,7 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene Sg, const dou
             hit[i] = h ? 1 : 0;
             Surface sf{{0, 0, 0}, {1, 0, 0}, 0};
             double col[3] = {1, 1, 1};
-            if (h) { sf = surface_at(S, r, q.best_t, q.id0, q.id1); const MaterialV m = material_at(S, sf.material); col[0] = m.colour[0]; col[1] = m.colour[1]; col[2] = m.colour[2]; }
+            if (h) { sf = surface_at<true>(S, r, q.best_t, q.id0, q.id1); MaterialV m = material_at(S, sf.material); if (m.texture >= 0) textured_colour(S, m, sf.u, sf.v, m.colour); col[0] = m.colour[0]; col[1] = m.colour[1]; col[2] = m.colour[2]; }
             t[i] = h ? q.best_t : 0.0;
             p[3 * i] = sf.p.x; p[3 * i + 1] = sf.p.y; p[3 * i + 2] = sf.p.z;
             nrm[3 * i] = sf.n.x; nrm[3 * i + 1] = sf.n.y; nrm[3 * i + 2] = sf.n.z;
@@ -889,7 +932,8 @@ void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayB
 }
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
                   uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
-    hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
+    auto k = L.variant == 0 ? k_shade<false, false> : L.variant == 1 ? k_shade<true, false> : L.variant == 2 ? k_shade<false, true> : k_shade<true, true>;
+    hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
 }
 void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, n_pix, spp, out_index, out_rgb);
@@ -913,9 +957,10 @@ int occupancy_blocks_closest(size_t lds_bytes) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest, kBlock, lds_bytes) != hipSuccess) n = 2;
     return clamp_blocks(n);
 }
-int occupancy_blocks_shade(size_t lds_bytes) {
+int occupancy_blocks_shade(size_t lds_bytes, int variant) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, lds_bytes) != hipSuccess) n = 2;
+    auto k = variant == 0 ? k_shade<false, false> : variant == 1 ? k_shade<true, false> : variant == 2 ? k_shade<false, true> : k_shade<true, true>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kBlock, lds_bytes) != hipSuccess) n = 2;
     return clamp_blocks(n);
 }
 } // namespace ftk

@@ -121,8 +121,21 @@ struct Flattener {
                 if (m.texture >= 0) m.hue_rot = (m.hue_rot + 1) % 3;
                 else { double r = m.colour[0], gg = m.colour[1], b = m.colour[2]; m.colour[0] = b; m.colour[1] = r; m.colour[2] = gg; }
             } else if (f.kind == GraphNode::Texture) {
-                out.any_texture = true;
-                m.texture = 0;
+                ftd::Texture t{};
+                for (int a = 0; a < 3; ++a) { t.c1[a] = f.node->ca[a]; t.c2[a] = f.node->cb[a]; }
+                const size_t n_ops = f.node->uv_ops.size() / 3;
+                if (n_ops > 5) { status = FT_ERR_UNSUPPORTED; err = "more than 5 nested texture functions"; return 0; }
+                t.n_ops = (double)n_ops;
+                for (size_t k = 0; k < n_ops; ++k) {
+                    const double kind = f.node->uv_ops[3 * k], a = f.node->uv_ops[3 * k + 1], b = f.node->uv_ops[3 * k + 2];
+                    t.ops[k][0] = kind;
+                    if (kind == 0.0) { t.ops[k][1] = a; t.ops[k][2] = b; }
+                    else { t.ops[k][1] = std::cos(a); t.ops[k][2] = std::sin(a); }   // matrix (rotate (0,1,0) angle), Transform.fs:60-69
+                }
+                size_t idx = 0;
+                for (; idx < out.textures.size(); ++idx) if (std::memcmp(&out.textures[idx], &t, sizeof t) == 0) break;
+                if (idx == out.textures.size()) out.textures.push_back(t);
+                m.texture = (int32_t)idx; m.hue_rot = 0;
             }
         }
         if (m.reflectance > 0.0 && m.apply_lighting) out.any_reflective = true;
@@ -327,8 +340,7 @@ int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
     if (f.max_csg_depth > 8) { err = "CSG nesting deeper than 8 levels is not supported on the device path"; return FT_ERR_UNSUPPORTED; }
     if (out.csg_capacity > 255) { err = "a CSG subtree can produce more than 255 hits per ray; lower csg_mesh_capacity"; return FT_ERR_UNSUPPORTED; }
     if (out.leaves.size() > ftd::ID_LEAF_MASK) { err = "too many primitive instances"; return FT_ERR_UNSUPPORTED; }
-    if (out.any_texture) { err = "textures (Scene.fs:44) are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
-    for (auto& m : out.materials) if (m.roughness != 0.0) { err = "roughness != 0 (Oren-Nayar, Shading.fs:50-63) is not on the device path yet"; return FT_ERR_UNSUPPORTED; }
+    if (out.textures.empty()) out.textures.push_back(ftd::Texture{});
     for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) { err = "softdirectional lights are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
     if (out.tris.empty()) { out.tris.assign(9, 0.0); out.tri_orig.assign(1, 0u); }   // keep device pointers non-null
     if (out.culls.empty()) out.culls.push_back(ftd::CullRecord{});

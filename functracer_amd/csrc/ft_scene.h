@@ -30,6 +30,7 @@ struct FlatScene {
     std::vector<double> m2w;          // 12 per leaf
     std::vector<ftd::Material> materials;
     std::vector<ftd::Light> lights;
+    std::vector<ftd::Texture> textures;
     std::vector<uint32_t> program;
     std::vector<ftd::Mesh> meshes;
     std::vector<ftd::BspNode> nodes;

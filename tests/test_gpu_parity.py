@@ -151,8 +151,6 @@ def _load(name):
 
 @pytest.mark.parametrize("name,w,h,spp", SMALL)
 def test_config_scene_frames_match_oracle(hip, name, w, h, spp):
-    if name == "sample-det":
-        pytest.xfail("grid textures (Scene.fs:44) are not on the device path yet")
     p = _load(name)
     orc = O.Oracle()
     p.lower(orc)
@@ -173,7 +171,7 @@ def test_golden_frames(hip):
     import os
     path = os.path.join(H.ROOT, "tests", "golden", "frames.npz")
     z = np.load(path)
-    for name, w, h, spp in [("hollow-sphere", 96, 54, 1), ("bunny", 96, 54, 2), ("night-house-det", 96, 54, 2)]:
+    for name, w, h, spp in [("hollow-sphere", 96, 54, 1), ("bunny", 96, 54, 2), ("night-house-det", 96, 54, 2), ("sample-det", 64, 64, 1)]:
         p = _load(name)
         p.lower(hip)
         got, _ = hip.render(p.camera, w, h, spp, z[name + "_jitter"])
@@ -253,3 +251,36 @@ def test_mesh_tie_break_follows_list_order(hip):
     got, want = hip.closest(o, d), orc.closest(o, d)
     assert want[0].all() and np.array_equal(want[3][:, 2], [1.0 if k % 2 == 0 else -1.0 for k in range(8)])
     assert np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
+
+
+def _textured_scene(b):
+    """Grid textures on every uv-carrying primitive (Sphere.fs:6-10, Plane.fs:28-33 through squares and discs),
+    nested texture functions, hueShift after a texture, and Oren-Nayar materials (Shading.fs:50-63)."""
+    b.clear()
+    tex = lambda node, ops: b.texture_grid((0.55, 1.0, 0.41), (0.78, 0.51, 1.0), ops, node)
+    objs = [
+        tex(b.translate((0, -1, 0), b.primitive(ft.PLANE)), [(0, 0.7, 0.35), (1, H.deg(30.0), 0.0)]),
+        tex(b.material(b.translate((-2.2, 0, 0), b.primitive(ft.SPHERE)), colour=(0, 0, 0), reflectance=0.1, shineyness=30), [(0, 0.2, 0.2)]),
+        b.hue_shift(1.0, tex(b.translate((0, 0, 0.5), b.rotate((1, 1, 0), H.deg(35.0), b.primitive(ft.CUBE))), [(0, 0.25, 0.25)])),
+        tex(b.translate((2.2, -0.7, 0), b.primitive(ft.SOLID_CYLINDER)), [(1, H.deg(-20.0), 0.0), (0, 0.3, 0.3)]),
+        b.material(b.translate((-1.0, 1.6, 1.0), b.scale(0.6, b.primitive(ft.SPHERE))), colour=(1, 1, 1), roughness=0.4),
+        b.material(b.translate((1.0, 1.6, 1.0), b.scale(0.6, b.primitive(ft.SPHERE))), colour=(0.9, 0.8, 0.7), roughness=0.8, shineyness=5),
+    ]
+    b.set_objects(b.group(objs))
+    b.add_directional((0.5, -1, 1), (1, 1, 1))
+    b.add_positional((0, 4, -4), (1, 0.05, 0.01), (0.6, 0.6, 0.9))
+    b.commit()
+
+
+def test_textures_and_oren_nayar(hip):
+    orc = O.Oracle()
+    for b in (orc, hip):
+        _textured_scene(b)
+    o, d = H.random_rays(20000, seed=21, origin_scale=3.0, toward=(0, 0, 0), spread=2.0)
+    H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="textured scene")     # includes the textured colour of each hit
+    cam = ft.make_camera((0, 2.5, -7), (0, 0, 0), (0, 1, 0), H.deg(55.0))
+    jit = ft.jitter_pattern(2)
+    want, _ = orc.render(cam, 160, 120, 2, jit)
+    got, st = hip.render(cam, 160, 120, 2, jit)
+    worst = H.assert_frames_match(got, want, what="textures + Oren-Nayar")
+    assert worst < 1e-6

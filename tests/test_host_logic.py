@@ -135,10 +135,11 @@ def test_host_only_context_never_renders():
 def test_unsupported_surface_is_rejected_loudly():
     ctx = ft.Context(host_only=True)
     ctx.clear()
-    ctx.set_objects(ctx.group([ctx.material(ctx.primitive(ft.SPHERE), roughness=0.4)]))
+    ctx.set_objects(ctx.group([ctx.primitive(ft.SPHERE)]))
+    ctx.add_soft_directional((0, -1, 0), 4, 0.1, (1, 1, 1))
     with pytest.raises(ft.FtError) as e:
         ctx.commit()
-    assert e.value.status == -4
+    assert e.value.status == -4 and "softdirectional" in str(e.value)
     with pytest.raises(ft.FtError):
         ctx.primitive(99)
     with pytest.raises(ft.FtError):
