@@ -192,7 +192,7 @@ class Context(SceneBuilder):
     def render(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None, out=None, fetch=True):
         """Program.fs:54-64 on the GPU.  Returns (rgb[res_v, res_h, 3] float64, stats dict).  With
         fetch=False the frame stays in HBM (returns (None, stats)); `fetch_frame` copies it out later."""
-        jitter = _capi.as_f64(jitter, (spp, 2))
+        jitter = np.zeros((1, 2)) if spp == 0 else _capi.as_f64(jitter, (spp, 2))   # spp == 0: `samples corner` (Image.fs:125-150)
         if fetch and out is None:
             out = np.zeros((res_v, res_h, 3))
         rects, n_rects = _capi.make_rects(tiles)

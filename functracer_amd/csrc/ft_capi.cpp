@@ -48,7 +48,8 @@ struct ft_context {
     // pixel list of the last render, cached across calls with the same resolution and tiles
     std::vector<uint32_t> pixels;
     std::vector<ft_rect> pixel_rects;
-    bool pixels_whole = false;
+    bool pixels_whole = false, pixels_corner = false;
+    DeviceBuf d_out_index;
     int64_t last_n_pix = 0;
     int32_t last_res_h = 0, last_res_v = 0;
     double k_ms[4] = {0, 0, 0, 0};
@@ -130,6 +131,8 @@ ftk::Camera make_camera(const ft_camera& cam, int res_h, int res_v) {
     out.pw = pixel_width; out.ph = pixel_height;
     out.tlx = -width / 2.0 + pixel_width / 2.0; out.tly = height / 2.0 - pixel_height / 2.0;
     out.res_h = res_h; out.res_v = res_v;
+    out.has_focus = cam.has_focus ? 1 : 0; out.focal_length = cam.focal_length;
+    out.tan_half_aperture = std::tan(cam.aperture_angular_size / 2.0);          // Jitter.fs:30
     return out;
 }
 
@@ -172,7 +175,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_out_index,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -310,6 +313,8 @@ int32_t ft_scene_commit(ft_context* c) {
     S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>(); S.tri_orig = c->d_tri_orig.as<uint32_t>();
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
+    S.shadow_rays_per_hit = 0;
+    for (auto& l : f.lights) S.shadow_rays_per_hit += (l.kind == ftd::LT_SOFT) ? l.samples : 1;   // Shading.fs:24-42
     c->committed = true;
     return FT_OK;
 }
@@ -333,14 +338,15 @@ int32_t ft_fetch_frame(ft_context* c, double* out_rgb) {
 
 // ------------------------------------------------------------------------------------------ render
 int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                  int32_t max_depth, uint64_t /*seed*/, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
+                  int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
     if (!c) return FT_ERR_INVALID;
-    if (!cam || !jitter_xy || res_h < 2 || res_v < 2 || spp < 1 || max_depth < 0 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
+    if (!cam || res_h < 2 || res_v < 2 || spp < 0 || (spp > 0 && !jitter_xy) || max_depth < 0 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
     if (max_depth > ftk::kMaxBounce) { c->err = "max_depth above 16"; return FT_ERR_UNSUPPORTED; }
     if ((int64_t)res_h * res_v > (int64_t)0x7FFFFFFF) { c->err = "resolution too large"; return FT_ERR_INVALID; }
     if (!need_device(c)) return FT_ERR_NO_DEVICE;
     if (!c->committed) { c->err = "scene not committed (ft_scene_commit)"; return FT_ERR_STATE; }
-    if (cam->has_focus) { c->err = "camera focus (depth of field, Image.fs:91-94) is not on the device path yet"; return FT_ERR_UNSUPPORTED; }
+    const bool corner = spp == 0;                                  // CornerSampling.strategy (Image.fs:125-150): one ray per pixel corner
+    if (corner) { spp = 1; }
     const auto wall0 = std::chrono::steady_clock::now();
     FT_HIP(c, hipSetDevice(c->device));
 
@@ -358,9 +364,29 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
         if (r.y0 + r.h > res_v) r.h = res_v - r.y0;
         if (r.w > 0 && r.h > 0) rects.push_back(r);
     }
-    const bool same_list = c->last_n_pix > 0 && c->last_res_h == res_h && c->last_res_v == res_v && c->pixels_whole == whole &&
+    const bool same_list = !corner && !c->pixels_corner && c->last_n_pix > 0 && c->last_res_h == res_h && c->last_res_v == res_v && c->pixels_whole == whole &&
                            c->pixel_rects.size() == rects.size() && (rects.empty() || std::memcmp(c->pixel_rects.data(), rects.data(), rects.size() * sizeof(ft_rect)) == 0);
-    if (!same_list) {
+    struct Job { uint32_t id_base, n_ids, w, h, out_base, n_out; };
+    std::vector<Job> jobs;
+    std::vector<uint32_t> corner_ids;
+    if (corner) {
+        // Each rect (split by rows so that its corner grid fits one chunk) is a job of (w+1) x (h+1) corner rays.
+        std::vector<uint32_t>& px = c->pixels;
+        px.clear();
+        const uint32_t cs = (uint32_t)res_h + 1;
+        for (const ft_rect& r : rects) {
+            int64_t max_rows = c->chunk_samples / (r.w + 1) - 1;
+            if (max_rows < 1) max_rows = 1;
+            for (int y0 = r.y0; y0 < r.y0 + r.h; y0 += (int)max_rows) {
+                const int h = (int)std::min<int64_t>(max_rows, r.y0 + r.h - y0);
+                Job j{(uint32_t)corner_ids.size(), (uint32_t)((r.w + 1) * (h + 1)), (uint32_t)r.w, (uint32_t)h, (uint32_t)px.size(), (uint32_t)(r.w * h)};
+                for (int y = y0; y <= y0 + h; ++y) for (int x = r.x0; x <= r.x0 + r.w; ++x) corner_ids.push_back((uint32_t)y * cs + (uint32_t)x);
+                for (int y = y0; y < y0 + h; ++y) for (int x = r.x0; x < r.x0 + r.w; ++x) px.push_back((uint32_t)(y * res_h + x));
+                jobs.push_back(j);
+            }
+        }
+        c->pixel_rects = rects; c->pixels_whole = whole; c->pixels_corner = true; c->last_n_pix = 0;
+    } else if (!same_list) {
         std::vector<uint32_t>& px = c->pixels;
         px.clear();
         for (const ft_rect& r : rects) {
@@ -371,7 +397,7 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
                 for (int y = r.y0; y < r.y0 + r.h; ++y) for (int x = r.x0; x < r.x0 + r.w; ++x) px.push_back((uint32_t)(y * res_h + x));
             }
         }
-        c->pixel_rects = rects; c->pixels_whole = whole; c->last_n_pix = 0;
+        c->pixel_rects = rects; c->pixels_whole = whole; c->pixels_corner = false; c->last_n_pix = 0;
     }
     const std::vector<uint32_t>& pixels = c->pixels;
     const int64_t n_pix_total = (int64_t)pixels.size();
@@ -381,12 +407,22 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
     int32_t rc;
     int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, c->chunk_samples / spp));
     if (pix_per_chunk > 64) pix_per_chunk -= pix_per_chunk % 64;      // keep 8x8 blocks (= wavefronts) whole
-    const int64_t cap = pix_per_chunk * spp;
+    int64_t cap = pix_per_chunk * spp;
+    if (corner) { cap = 1; for (auto& j : jobs) cap = std::max<int64_t>(cap, j.n_ids); }
+    else for (int64_t p0 = 0; p0 < n_pix_total; p0 += pix_per_chunk) {
+        const uint32_t n = (uint32_t)std::min<int64_t>(pix_per_chunk, n_pix_total - p0);
+        jobs.push_back(Job{(uint32_t)p0, n, 0, 0, (uint32_t)p0, n});
+    }
     if (cap > 0x7FFFFFFFll) { c->err = "chunk too large"; return FT_ERR_INVALID; }
     if ((rc = ensure_frame_buffers(c, cap)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_out, (size_t)(whole ? (int64_t)res_h * res_v : n_pix_total) * 24)) != FT_OK) return rc;
-    if (!same_list) { if ((rc = upload(c, c->d_pixels, pixels)) != FT_OK) return rc; }
-    std::vector<double> jit(jitter_xy, jitter_xy + 2 * (size_t)spp);
+    if (corner) {
+        if ((rc = upload(c, c->d_pixels, corner_ids)) != FT_OK) return rc;
+        if ((rc = upload(c, c->d_out_index, pixels)) != FT_OK) return rc;
+    } else if (!same_list) { if ((rc = upload(c, c->d_pixels, pixels)) != FT_OK) return rc; }
+    std::vector<double> jit;
+    if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
+    else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
     if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
     FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
 
@@ -394,6 +430,7 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
     const size_t lds = lds_bytes_for(c->flat);
     int variant = 0;
     for (auto& m : c->flat.materials) { if (m.roughness != 0.0) variant |= 1; if (m.texture >= 0) variant |= 2; }
+    for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 4;
     ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds), lds, 0};
     ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds, variant), lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
@@ -417,11 +454,13 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
     hipEvent_t ev0 = next_event(c), ev1 = next_event(c);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     int n_chunks = 0, n_launches = 0;
-    for (int64_t p0 = 0; p0 < n_pix_total; p0 += pix_per_chunk, ++n_chunks) {
-        const uint32_t n_pix = (uint32_t)std::min<int64_t>(pix_per_chunk, n_pix_total - p0);
+    for (const Job& job : jobs) {
+        ++n_chunks;
+        const uint32_t n_pix = job.n_ids;
         const uint32_t n_samples = n_pix * (uint32_t)spp;
         FT_HIP(c, hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream));
-        const ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), (uint32_t)p0, n_pix, spp};
+        const ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
+                               (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed};
         timed(0, [&] { (void)hipMemsetAsync(c->d_acc.p, 0, (size_t)n_samples * 24, c->stream); });   // accumulators start at Colour.Zero
         ++n_launches;
         for (int b = 0; b <= last_bounce; ++b) {
@@ -429,8 +468,10 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
             n_launches += 2;
         }
-        timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, whole ? c->d_pixels.as<uint32_t>() + p0 : nullptr,
-                                             whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * p0); });
+        const uint32_t* out_index = !whole ? nullptr : (corner ? c->d_out_index.as<uint32_t>() : c->d_pixels.as<uint32_t>()) + job.out_base;
+        double* out_ptr = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
+        if (corner) timed(3, [&] { ftk::launch_blend_corner(Lg, c->d_acc.as<double>(), n_samples, job.w, job.h, out_index, out_ptr); });
+        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, out_index, out_ptr); });
         ++n_launches;
     }
     if (ev1) (void)hipEventRecord(ev1, c->stream);
@@ -446,7 +487,7 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
     if (stats) {
         float ms = 0;
         if (ev0 && ev1) (void)hipEventElapsedTime(&ms, ev0, ev1);
-        stats->rays_primary = (uint64_t)n_pix_total * (uint64_t)spp;
+        stats->rays_primary = 0; for (auto& j : jobs) stats->rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;
         stats->rays_shadow = hrc.rays_shadow; stats->rays_reflect = hrc.rays_reflect;
         stats->rays_traced = stats->rays_primary + stats->rays_shadow + stats->rays_reflect;
         stats->rays_reference_equivalent = (double)stats->rays_primary + hrc.ref_equiv;

@@ -26,6 +26,7 @@ struct DevScene {
     const double* culls;           // 24 doubles per ftd::CullRecord
     const uint32_t* tri_orig;      // 1 per triangle
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
+    int32_t shadow_rays_per_hit, pad;   // sum over lights of the shadow rays the reference casts per hit
 };
 
 // Ray wavefront buffer, struct-of-arrays so a wave's 64 records are 512 contiguous bytes per field.
@@ -51,14 +52,16 @@ struct RenderCounters {
 struct Camera {                    // ImagePlane (Image.fs:55-63), computed on the host
     double o[3], k[3], i[3], j[3];
     double pw, ph, tlx, tly;
+    double focal_length, tan_half_aperture;   // Image.Focus (Image.fs:9), tan (apetureAngularSize / 2) from the host
     int32_t res_h, res_v;
+    int32_t has_focus, pad;
 };
 
 struct Launch {
     hipStream_t stream;
     int grid;                      // persistent grid size (workgroups)
     size_t lds_bytes;
-    int variant;                   // k_shade: bit 0 = Oren-Nayar compiled in, bit 1 = textures compiled in
+    int variant;                   // k_shade: bit 0 = Oren-Nayar, bit 1 = textures, bit 2 = soft lights compiled in
 };
 
 // Everything bounce 0 needs to regenerate a primary ray from its sample index i = s*n_pix + pixel.
@@ -68,6 +71,8 @@ struct Primary {
     const double* jitter;          // spp x 2, the ONE pattern shared by every pixel (Image.fs:105)
     uint32_t pix_base, n_pix;
     int32_t spp;
+    uint32_t stride;               // ids are y*stride + x: res_h for pixels, res_h + 1 for the corner grid of `samples corner`
+    unsigned long long seed;       // keys the counter-based streams of soft shadows / depth of field
 };
 // K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.
 void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce,
@@ -78,6 +83,8 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
 // out_index == nullptr: pixel p is written at out_rgb + 3p (packed); else at out_rgb + 3*out_index[p] (in place in the frame).
 void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb);
+// CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
+void launch_blend_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,
                           int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc);

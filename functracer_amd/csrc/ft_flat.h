@@ -72,7 +72,7 @@ struct Light {             // Light.fs:7-14; 96 bytes
     double scatter;
     uint32_t kind;
     int32_t samples;
-    double pad;
+    double tan_half_scatter;  // tan (scattering / 2) (Jitter.fs:30), evaluated on the host
 };
 
 struct Mesh {

@@ -677,17 +677,63 @@ FT_DEV void wave_add(unsigned long long* dst, unsigned long long v_per_lane_flag
 }
 
 // ---------------------------------------------------------------------------------------------
+// Seeded counter-based stream standing in for the reference's unseeded System.Random (Jitter.fs:27, Image.fs:101):
+//   key = sm64(sm64(sm64(seed ^ sample) ^ (depth << 32 | light << 8 | purpose)));  u_n = (sm64(key + n) >> 11) * 2^-53
+// (sm64 = splitmix64's output function; sample = pixel_id * spp + s; purpose 1 = soft shadow, 2 = depth of field).
+// Every draw is a pure function of its key, so frames do not depend on tiling, chunking or traversal order.
+FT_DEV unsigned long long sm64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    unsigned long long key, n;
+    FT_DEV double next() { return (double)(sm64(key + n++) >> 11) * (1.0 / 9007199254740992.0); }
+};
+FT_DEV Rng make_rng(unsigned long long seed, unsigned long long sample, uint32_t depth, uint32_t light, uint32_t purpose) {
+    return {sm64(sm64(sm64(seed ^ sample) ^ (((unsigned long long)depth << 32) | ((unsigned long long)light << 8) | purpose))), 0ull};
+}
+// Jitter.jitterVector (Jitter.fs:26-39): the orthonormal frame around `v`, then one direction per call of jittered().
+struct JitterFrame {
+    V3 nv, i, j; double m;
+    FT_DEV JitterFrame(V3 v, double tan_half_angle) {
+        nv = normalise(v); m = tan_half_angle;
+        const V3 g = nv.x > 0.9 ? V3{0.0, 1.0, 0.0} : V3{1.0, 0.0, 0.0};
+        i = normalise(V3{g.y * nv.z - g.z * nv.y, nv.x * g.z - nv.z * g.x, g.x * nv.y - g.y * nv.x});          // generator .** normalised
+        j = V3{i.y * nv.z - i.z * nv.y, nv.x * i.z - nv.z * i.x, i.x * nv.y - i.y * nv.x};                     // i .** normalised
+    }
+    FT_DEV V3 jittered(Rng& rng) const {
+        double x, y;
+        for (;;) { x = 2.0 * rng.next() - 1.0; y = 2.0 * rng.next() - 1.0; if ((x * x + y * y) > 1.0) continue; break; }   // Jitter.circle (Jitter.fs:15-21)
+        const double a = m * x, b = m * y;
+        return normalise(V3{(nv.x + a * i.x) + b * j.x, (nv.y + a * i.y) + b * j.y, (nv.z + a * i.z) + b * j.z});
+    }
+};
+FT_DEV unsigned long long sample_id(const Primary& g, uint32_t slot) {
+    const uint32_t s = slot / g.n_pix, pl = slot - s * g.n_pix;
+    return (unsigned long long)g.pixel_ids[g.pix_base + pl] * (unsigned long long)g.spp + s;
+}
+
 // Primary rays are never stored: bounce 0 of k_closest / k_shade regenerates them from the sample index
 // (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
 // 64 pixels of one 8x8 block for one jitter offset).
 FT_DEV Ray primary_ray(const Primary& g, uint32_t i) {
     const uint32_t s = i / g.n_pix, pl = i - s * g.n_pix;
     const uint32_t pid = g.pixel_ids[g.pix_base + pl];
-    const uint32_t py = pid / (uint32_t)g.cam.res_h, px = pid - py * (uint32_t)g.cam.res_h;
+    const uint32_t py = pid / g.stride, px = pid - py * g.stride;
     const double centre_x = g.cam.tlx + (double)px * g.cam.pw, centre_y = g.cam.tly - (double)py * g.cam.ph;
     const double jx = centre_x + g.jitter[2 * s] * g.cam.pw, jy = centre_y + g.jitter[2 * s + 1] * g.cam.ph;
-    return {g.cam.o[0], g.cam.o[1], g.cam.o[2],
-            (g.cam.k[0] + jx * g.cam.i[0]) + jy * g.cam.j[0], (g.cam.k[1] + jx * g.cam.i[1]) + jy * g.cam.j[1], (g.cam.k[2] + jx * g.cam.i[2]) + jy * g.cam.j[2]};
+    Ray r{g.cam.o[0], g.cam.o[1], g.cam.o[2],
+          (g.cam.k[0] + jx * g.cam.i[0]) + jy * g.cam.j[0], (g.cam.k[1] + jx * g.cam.i[1]) + jy * g.cam.j[1], (g.cam.k[2] + jx * g.cam.i[2]) + jy * g.cam.j[2]};
+    if (g.cam.has_focus) {                                         // ImagePlane.depthOfFieldJitter (Image.fs:91-94, Ray.fs:15-18)
+        Rng rng = make_rng(g.seed, (unsigned long long)pid * (unsigned long long)g.spp + s, 0u, 0u, 2u);
+        const double f = g.cam.focal_length;
+        const V3 o1{r.ox + f * r.dx, r.oy + f * r.dy, r.oz + f * r.dz};                               // shiftOrigin focalLength
+        const V3 d1 = JitterFrame(V3{r.dx, r.dy, r.dz}, g.cam.tan_half_aperture).jittered(rng);        // jitterDirection
+        r = {o1.x + -f * d1.x, o1.y + -f * d1.y, o1.z + -f * d1.z, d1.x, d1.y, d1.z};                  // shiftOrigin -focalLength
+    }
+    return r;
 }
 
 __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
@@ -742,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, Ra
 
 // ROUGH / TEXTURED select the variants with Oren-Nayar and grid textures compiled in: they need libm-heavy
 // code (acos, tan, atan2 ...) whose registers would otherwise halve the occupancy of every scene.
-template <bool ROUGH, bool TEXTURED>
+template <bool ROUGH, bool TEXTURED, bool SOFT>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
                                                    double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
                                                    ChunkCounters* cc, RenderCounters* rc) {
@@ -778,7 +824,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
         const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
         for (int l = 0; l < n_lights; ++l) {                       // wave-uniform
             cdp lp = S.lights + 12ull * (uint32_t)l;                 // wave-uniform: scalar loads
-            struct { double v[3], falloff[3], colour[3]; uint32_t kind; } lt = {{lp[0], lp[1], lp[2]}, {lp[3], lp[4], lp[5]}, {lp[6], lp[7], lp[8]}, reinterpret_cast<cup>(lp + 10)[0]};
+            struct { double v[3], falloff[3], colour[3]; uint32_t kind; int32_t samples; double tan_half_scatter; } lt =
+                {{lp[0], lp[1], lp[2]}, {lp[3], lp[4], lp[5]}, {lp[6], lp[7], lp[8]}, reinterpret_cast<cup>(lp + 10)[0], reinterpret_cast<cip>(lp + 10)[1], lp[11]};
             if (active && !lit) { cr += mat.colour[0]; cg += mat.colour[1]; cb += mat.colour[2]; }   // shadeIfRequired (Shading.fs:100-104)
             Query<true> q;
             q.active = lit; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0;
@@ -797,8 +844,25 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
                 ld = {lt.v[0], lt.v[1], lt.v[2]};
             }
             bool overflow = false;
-            if (__any(lit)) trace<true>(S, sr, q, lds, overflow, bounce == 0);
-            n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
+            if (SOFT && lt.kind == LT_SOFT) {                      // softShadowLightIntensity (Shading.fs:24-31)
+                const JitterFrame frame(V3{-lt.v[0], -lt.v[1], -lt.v[2]}, lt.tan_half_scatter);
+                Rng rng = make_rng(gen.seed, active ? sample_id(gen, slot) : 0ull, (uint32_t)bounce, (uint32_t)l, 1u);
+                int occluded = 0;
+                for (int k = 0; k < lt.samples; ++k) {             // wave-uniform count; each lane draws its own direction
+                    const V3 dj = frame.jittered(rng);
+                    Query<true> qs;
+                    qs.active = lit; qs.blocked = false; qs.best_t = 0; qs.id0 = 0; qs.id1 = 0; qs.max_dist = 1.7976931348623157e308;
+                    bool ovf = false;
+                    if (__any(lit)) trace<true>(S, Ray{sox, soy, soz, dj.x, dj.y, dj.z}, qs, lds, ovf, false);
+                    if (qs.blocked) ++occluded;
+                    overflow = overflow || ovf;
+                    n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
+                }
+                intensity = (double)(lt.samples - occluded) / (double)lt.samples;
+            } else {
+                if (__any(lit)) trace<true>(S, sr, q, lds, overflow, bounce == 0);
+                n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
+            }
             n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && lit));
             if (lit) {
                 if (q.blocked) intensity = 0.0;
@@ -861,7 +925,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
     // and each reflective hit L reflection rays (Shading.fs:109-139).
     if (lane_id() == 0 && (n_hit_wave || n_refl_wave)) {
         const double mult = pow((double)n_lights, (double)bounce);
-        atomicAdd(&rc->ref_equiv, mult * (double)n_lights * ((double)n_hit_wave + (double)n_refl_wave));
+        atomicAdd(&rc->ref_equiv, mult * ((double)Sg.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave));
     }
 }
 
@@ -874,6 +938,19 @@ __global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc
         }
         const size_t o = out_index ? out_index[p] : p;
         out[3 * o] = r / (double)spp; out[3 * o + 1] = g / (double)spp; out[3 * o + 2] = b / (double)spp;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_blend_corner(const double* __restrict__ acc, uint32_t acc_stride, uint32_t w, uint32_t h,
+                                                          const uint32_t* __restrict__ out_index, double* __restrict__ out) {
+    const uint32_t n = w * h, cs = w + 1;
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
+        const uint32_t y = p / w, x = p - y * w;
+        const uint32_t c[4] = {y * cs + x, y * cs + x + 1, (y + 1) * cs + x, (y + 1) * cs + x + 1};   // Image.fs:139
+        double r = 0.0, g = 0.0, b = 0.0;                          // Seq.average: sum in corner order, / 4
+        for (int k = 0; k < 4; ++k) { r += acc[c[k]]; g += acc[(size_t)acc_stride + c[k]]; b += acc[2 * (size_t)acc_stride + c[k]]; }
+        const size_t o = out_index ? out_index[p] : p;
+        out[3 * o] = r / 4.0; out[3 * o + 1] = g / 4.0; out[3 * o + 2] = b / 4.0;
     }
 }
 
@@ -924,6 +1001,20 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
 
 } // namespace
 
+typedef void (*ShadeKernel)(DevScene, Primary, RayBuf, HitBuf, const uint32_t*, RayBuf, double*, uint32_t, int, int, ChunkCounters*, RenderCounters*);
+static ShadeKernel shade_variant(int v) {
+    switch (v & 7) {
+        case 0: return k_shade<false, false, false>;
+        case 1: return k_shade<true, false, false>;
+        case 2: return k_shade<false, true, false>;
+        case 3: return k_shade<true, true, false>;
+        case 4: return k_shade<false, false, true>;
+        case 5: return k_shade<true, false, true>;
+        case 6: return k_shade<false, true, true>;
+        default: return k_shade<true, true, true>;
+    }
+}
+
 // ============================================================================================ launchers
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
@@ -932,11 +1023,14 @@ void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayB
 }
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
                   uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
-    auto k = L.variant == 0 ? k_shade<false, false> : L.variant == 1 ? k_shade<true, false> : L.variant == 2 ? k_shade<false, true> : k_shade<true, true>;
+    auto k = shade_variant(L.variant);
     hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
 }
 void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, n_pix, spp, out_index, out_rgb);
+}
+void launch_blend_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb) {
+    hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, w, h, out_index, out_rgb);
 }
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n, int32_t* hit, double* t,
                           double* p, double* nrm, double* colour, RenderCounters* rc) {
@@ -959,7 +1053,7 @@ int occupancy_blocks_closest(size_t lds_bytes) {
 }
 int occupancy_blocks_shade(size_t lds_bytes, int variant) {
     int n = 0;
-    auto k = variant == 0 ? k_shade<false, false> : variant == 1 ? k_shade<true, false> : variant == 2 ? k_shade<false, true> : k_shade<true, true>;
+    auto k = shade_variant(variant);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kBlock, lds_bytes) != hipSuccess) n = 2;
     return clamp_blocks(n);
 }

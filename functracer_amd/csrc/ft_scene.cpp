@@ -123,8 +123,8 @@ struct Flattener {
             } else if (f.kind == GraphNode::Texture) {
                 ftd::Texture t{};
                 for (int a = 0; a < 3; ++a) { t.c1[a] = f.node->ca[a]; t.c2[a] = f.node->cb[a]; }
-                const size_t n_ops = f.node->uv_ops.size() / 3;
-                if (n_ops > 5) { status = FT_ERR_UNSUPPORTED; err = "more than 5 nested texture functions"; return 0; }
+                size_t n_ops = f.node->uv_ops.size() / 3;
+                if (n_ops > 5) { status = FT_ERR_UNSUPPORTED; err = "more than 5 nested texture functions on one grid texture"; n_ops = 5; }   // flatten fails; keep the record well-formed
                 t.n_ops = (double)n_ops;
                 for (size_t k = 0; k < n_ops; ++k) {
                     const double kind = f.node->uv_ops[3 * k], a = f.node->uv_ops[3 * k + 1], b = f.node->uv_ops[3 * k + 2];
@@ -341,7 +341,7 @@ int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
     if (out.csg_capacity > 255) { err = "a CSG subtree can produce more than 255 hits per ray; lower csg_mesh_capacity"; return FT_ERR_UNSUPPORTED; }
     if (out.leaves.size() > ftd::ID_LEAF_MASK) { err = "too many primitive instances"; return FT_ERR_UNSUPPORTED; }
     if (out.textures.empty()) out.textures.push_back(ftd::Texture{});
-    for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) { err = "softdirectional lights are not on the device path yet"; return FT_ERR_UNSUPPORTED; }
+    for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) l.tan_half_scatter = std::tan(l.scatter / 2.0);
     if (out.tris.empty()) { out.tris.assign(9, 0.0); out.tri_orig.assign(1, 0u); }   // keep device pointers non-null
     if (out.culls.empty()) out.culls.push_back(ftd::CullRecord{});
     return FT_OK;

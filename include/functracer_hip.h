@@ -86,8 +86,9 @@ typedef struct ft_material {
     int32_t _pad;
 } ft_material;
 
-/* Image.Camera (Image.fs:10-17).  focus (depth of field, Image.fs:91-94) draws from an unseeded
- * System.Random in the reference; has_focus != 0 is rejected with FT_ERR_UNSUPPORTED this round. */
+/* Image.Camera (Image.fs:10-17).  focus = depth of field (Image.fs:91-94); the reference draws its
+ * direction jitter from an unseeded System.Random, here it comes from the seeded stream keyed by
+ * ft_render's `seed`. */
 typedef struct ft_camera {
     double o[3];
     double look_at[3];
@@ -157,7 +158,8 @@ int32_t ft_scene_commit(ft_context* ctx);
 
 /* ---- render (Program.fs:54-64) ----------------------------------------------------------- */
 /* res_h x res_v is Image.Resolution (Image.fs:28).  jitter_xy = spp x 2 offsets, the ONE pattern
- * shared by every pixel (Image.fs:105).  max_depth = the recursion limit (8 in Shading.fs:142).
+ * shared by every pixel (Image.fs:105); spp == 0 selects `samples corner` (CornerSampling, Image.fs:125-150:
+ * one ray per pixel corner, jitter_xy ignored).  max_depth = the recursion limit (8 in Shading.fs:142).
  * seed keys the counter-based streams of soft lights.  tiles == NULL renders the whole frame;
  * otherwise only pixels inside the n_tiles rects are written.  out_rgb is res_v x res_h x 3
  * doubles, row 0 = top (Image.fs:39).  out_rgb may be NULL: the frame then stays in HBM until

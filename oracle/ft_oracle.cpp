@@ -15,7 +15,8 @@
 //   * Sorting sequences that contain NaN keys is left undefined (the reference's behaviour
 //     there depends on F#'s generic comparison of NaN).
 //   * System.Random streams are unseeded in the reference (Image.fs:101, Jitter.fs:27): the
-//     jitter pattern is an explicit input; soft lights / depth of field are not restated yet.
+//     jitter pattern is an explicit input; soft lights / depth of field draw from the seeded
+//     counter-based stream documented at `struct Rng` below.
 #include "ft_oracle.h"
 
 #include <algorithm>
@@ -501,6 +502,43 @@ Geometry constructedSolid(Rule (*rules)(IType), Geometry a, Geometry b) {       
 struct Light { int kind; V3 v; double falloff[3]; V3 colour; int samples; double scatter; }; // 0 directional, 1 soft, 2 point
 inline double attenuate(const double f[3], double distance) { return 1.0 / (f[0] + distance * (f[1] + distance * f[2])); } // Light.fs:16-17
 
+// ---------------------------------------------------------------- Jitter.fs on a seeded counter-based stream
+// The reference draws from `System.Random()` (unseeded: Jitter.fs:27, Image.fs:101), so no two runs of it
+// agree.  Here every draw is a pure function of (seed, sample id, depth, light index, purpose, draw number):
+//   key = sm64(sm64(sm64(seed ^ sample) ^ (depth << 32 | light << 8 | purpose)));  u_n = (sm64(key + n) >> 11) * 2^-53
+// with sm64 = splitmix64's output function.  The same definition is implemented independently in the HIP
+// path (ft_kernels.hip); sample = pixel_id * spp + s, purpose 1 = soft shadow, 2 = depth of field.
+inline uint64_t sm64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t key, n;
+    Rng(uint64_t seed, uint64_t sample, uint32_t depth, uint32_t light, uint32_t purpose)
+        : key(sm64(sm64(sm64(seed ^ sample) ^ (((uint64_t)depth << 32) | ((uint64_t)light << 8) | purpose)))), n(0) {}
+    double nextDouble() { return (double)(sm64(key + n++) >> 11) * (1.0 / 9007199254740992.0); }   // [0,1) like Random.NextDouble
+};
+inline double uniform(Rng& r) { return 2.0 * r.nextDouble() - 1.0; }             // Jitter.fs:9-10
+inline void jitterCircle(Rng& r, double& x, double& y) {                         // Jitter.circle, Jitter.fs:15-21 (rejection)
+    for (;;) { x = uniform(r); y = uniform(r); if ((x * x + y * y) > 1.0) continue; return; }
+}
+std::vector<V3> jitterVector(Rng& random, int count, double maxAngle, V3 vector) {   // Jitter.fs:26-39
+    V3 normalised = normalise(vector);
+    double maxOffsetMagnitude = std::tan(maxAngle / 2.0);
+    V3 generator = (normalised.x > 0.9) ? V3{0, 1, 0} : V3{1, 0, 0};
+    V3 i = normalise(cross(generator, normalised));
+    V3 j = cross(i, normalised);
+    std::vector<V3> out;
+    for (int k = 0; k < count; ++k) {                                            // Jitter.pattern random circle count
+        double x, y; jitterCircle(random, x, y);
+        out.push_back(normalise(add(add(normalised, scale(i, maxOffsetMagnitude * x)), scale(j, maxOffsetMagnitude * y))));
+    }
+    return out;
+}
+struct Stream { uint64_t seed, sample; int maxDepth; };                          // identifies the ray tree a draw belongs to
+
 // ---------------------------------------------------------------- Scene.fs
 bool closest(Hits& hits, Hit& out) {                                             // Scene.fs:112-116
     std::stable_sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.t < b.t; });
@@ -608,7 +646,14 @@ bool lightIsBlocked(fto_context* ctx, double maxDistance, const Ray& ray) {     
 }
 
 // ---------------------------------------------------------------- Shading.fs
-double shadowLightIntensity(fto_context* ctx, const Light& light, V3 point) {    // Shading.fs:33-42
+double shadowLightIntensity(fto_context* ctx, const Light& light, V3 point, const Stream& st, int depth, int lightIndex) {   // Shading.fs:24-42
+    if (light.kind == 1) {                                                       // softShadowLightIntensity, Shading.fs:24-31
+        Rng rng(st.seed, st.sample, (uint32_t)depth, (uint32_t)lightIndex, 1);
+        int occluded = 0;
+        for (V3 d : jitterVector(rng, light.samples, light.scatter, neg(light.v)))
+            if (lightIsBlocked(ctx, std::numeric_limits<double>::max(), Ray{point, d})) ++occluded;
+        return (double)(light.samples - occluded) / (double)light.samples;
+    }
     if (light.kind == 0) return lightIsBlocked(ctx, std::numeric_limits<double>::max(), Ray{point, neg(light.v)}) ? 0.0 : 1.0;
     V3 d = psub(light.v, point);
     double distance = length(d);
@@ -655,9 +700,9 @@ V3 specularShader(const Fragment& f) {                                          
     return scale(f.lightColour, intensity);
 }
 
-V3 getColourForRay(fto_context* ctx, int recursionLimit, const Ray& ray);
+V3 getColourForRay(fto_context* ctx, int recursionLimit, const Ray& ray, const Stream& st);
 
-V3 shadeFragment(fto_context* ctx, int recursionLimit, const Fragment& f) {      // shadeIfRequired(multiPartShader [specular; reflection; diffuse]); Shading.fs:100-107, Program.fs:59
+V3 shadeFragment(fto_context* ctx, int recursionLimit, const Fragment& f, const Stream& st) {      // shadeIfRequired(multiPartShader [specular; reflection; diffuse]); Shading.fs:100-107, Program.fs:59
     const Hit& ix = *f.intersection;
     if (!ix.material.applyLighting) return ix.material.colour;
     V3 sum = {0, 0, 0};                                                          // Seq.sumBy starts from Zero
@@ -668,7 +713,7 @@ V3 shadeFragment(fto_context* ctx, int recursionLimit, const Fragment& f) {     
         V3 c = {0, 0, 0};                                                        // getColourForDirection, Shading.fs:132-134
         if (!(recursionLimit <= 0)) {
             ctx->counters.reflect.fetch_add(1, std::memory_order_relaxed);
-            c = getColourForRay(ctx, recursionLimit - 1, Ray{ix.p, reflectedDirection});
+            c = getColourForRay(ctx, recursionLimit - 1, Ray{ix.p, reflectedDirection}, st);
         }
         refl = scale(c, ix.material.reflectance);
     }
@@ -677,7 +722,7 @@ V3 shadeFragment(fto_context* ctx, int recursionLimit, const Fragment& f) {     
     return sum;
 }
 
-V3 getColourForRay(fto_context* ctx, int recursionLimit, const Ray& ray) {       // Shading.fs:131-139
+V3 getColourForRay(fto_context* ctx, int recursionLimit, const Ray& ray, const Stream& st) {   // Shading.fs:131-139
     Ray offset{add(ray.o, scale(ray.d, 0.0001)), ray.d};                         // slightOffset, Shading.fs:129
     Hits hits;
     ctx->geometry(offset, hits);
@@ -685,10 +730,11 @@ V3 getColourForRay(fto_context* ctx, int recursionLimit, const Ray& ray) {      
     if (!closest(hits, ix)) return {0, 0, 0};
     V3 shadowRayOrigin = add(ix.p, scale(ix.n, 0.0001));                         // getLightsOnPoint, Shading.fs:109-117
     V3 total = {0, 0, 0};
+    int lightIndex = 0;
     for (const Light& light : ctx->lights) {                                     // createFragments + Seq.sumBy shader, Shading.fs:119-127,139
-        double intensity = shadowLightIntensity(ctx, light, shadowRayOrigin);
+        double intensity = shadowLightIntensity(ctx, light, shadowRayOrigin, st, st.maxDepth - recursionLimit, lightIndex++);
         Fragment f{&ix, scale(light.colour, intensity), lightDirection(light, ix.p), &ray};
-        total = add(total, shadeFragment(ctx, recursionLimit, f));
+        total = add(total, shadeFragment(ctx, recursionLimit, f, st));
     }
     return total;
 }
@@ -770,9 +816,10 @@ int32_t fto_scene_add_directional(fto_context* c, const double dir[3], const dou
     Light l{}; l.kind = 0; l.v = normalise(V3{dir[0], dir[1], dir[2]}); l.colour = {colour[0], colour[1], colour[2]};
     c->lights.push_back(l); return FT_OK;
 }
-int32_t fto_scene_add_soft_directional(fto_context* c, const double*, int32_t, double, const double*) {
-    setErr(c, "softDirectional lights draw from an unseeded System.Random (Jitter.fs:27); not restated yet");
-    return FT_ERR_UNSUPPORTED;
+int32_t fto_scene_add_soft_directional(fto_context* c, const double dir[3], int32_t samples, double scatter_rad, const double colour[3]) {  // Light.fs:22-23
+    if (!c || !dir || !colour || samples < 1) return FT_ERR_INVALID;
+    Light l{}; l.kind = 1; l.v = normalise(V3{dir[0], dir[1], dir[2]}); l.colour = {colour[0], colour[1], colour[2]}; l.samples = samples; l.scatter = scatter_rad;
+    c->lights.push_back(l); return FT_OK;
 }
 int32_t fto_scene_add_positional(fto_context* c, const double pos[3], const double falloff[3], const double colour[3]) { // Light.fs:25-26
     if (!c || !pos || !falloff || !colour) return FT_ERR_INVALID;
@@ -788,18 +835,30 @@ int32_t fto_scene_commit(fto_context* c) {
 }
 
 int32_t fto_render(fto_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                   int32_t max_depth, uint64_t, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, int32_t threads, fto_stats* stats) {
-    if (!c || !cam || !jitter_xy || !out_rgb || res_h < 2 || res_v < 2 || spp < 1) return FT_ERR_INVALID;
+                   int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, int32_t threads, fto_stats* stats) {
+    if (!c || !cam || !out_rgb || res_h < 2 || res_v < 2 || spp < 0 || (spp > 0 && !jitter_xy)) return FT_ERR_INVALID;
     if (!c->committed) { setErr(c, "scene not committed"); return FT_ERR_STATE; }
-    if (cam->has_focus) { setErr(c, "depth of field not restated"); return FT_ERR_UNSUPPORTED; }
     auto t0 = std::chrono::steady_clock::now();
+    const bool corner = spp == 0;                                                // CornerSampling.strategy, Image.fs:125-150
     ImagePlane ip = imagePlaneCreate(*cam, res_h, res_v);
     // pixel list in y-major, x order (Image.fs:104), restricted to the tiles
     std::vector<int32_t> pixels;
     if (!tiles || n_tiles <= 0) { pixels.resize((size_t)res_h * res_v); for (size_t i = 0; i < pixels.size(); ++i) pixels[i] = (int32_t)i; }
     else for (int k = 0; k < n_tiles; ++k) for (int y = tiles[k].y0; y < tiles[k].y0 + tiles[k].h; ++y) for (int x = tiles[k].x0; x < tiles[k].x0 + tiles[k].w; ++x)
         if (x >= 0 && x < res_h && y >= 0 && y < res_v) pixels.push_back(y * res_h + x);
-    const int64_t nRays = (int64_t)pixels.size() * spp;
+    // The rays to shade: spp jittered rays per pixel (Image.fs:100-110), or one ray per pixel CORNER (Image.fs:128-132).
+    const int stride = res_h + 1;
+    std::vector<int32_t> corners;                                                // corner ids y*stride + x needed by the tile pixels
+    std::vector<int32_t> cornerSlot;
+    if (corner) {
+        cornerSlot.assign((size_t)stride * (res_v + 1), -1);
+        for (int32_t pix : pixels) {
+            int x = pix % res_h, y = pix / res_h;
+            for (int id : {y * stride + x, y * stride + x + 1, (y + 1) * stride + x, (y + 1) * stride + x + 1})
+                if (cornerSlot[(size_t)id] < 0) { cornerSlot[(size_t)id] = (int32_t)corners.size(); corners.push_back(id); }
+        }
+    }
+    const int64_t nRays = corner ? (int64_t)corners.size() : (int64_t)pixels.size() * spp;
     std::vector<V3> colours((size_t)nRays);
     c->counters.shadow = 0; c->counters.reflect = 0;
     int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
@@ -812,9 +871,23 @@ int32_t fto_render(fto_context* c, const ft_camera* cam, int32_t res_h, int32_t 
             if (begin >= nRays) break;
             int64_t end = std::min(begin + chunk, nRays);
             for (int64_t r = begin; r < end; ++r) {
-                int32_t pix = pixels[(size_t)(r / spp)]; int s = (int)(r % spp);
-                Ray ray = rayThroughPixel(ip, pix % res_h, pix / res_h, jitter_xy[2 * s], jitter_xy[2 * s + 1]);
-                colours[(size_t)r] = getColourForRay(c, max_depth, ray);         // shadeRay, Shading.fs:142
+                Ray ray; uint64_t sample;
+                if (corner) {
+                    int32_t id = corners[(size_t)r];
+                    ray = rayThroughPixel(ip, id % stride, id / stride, -0.5, 0.5);             // Image.fs:131
+                    sample = (uint64_t)id;
+                } else {
+                    int32_t pix = pixels[(size_t)(r / spp)]; int s = (int)(r % spp);
+                    ray = rayThroughPixel(ip, pix % res_h, pix / res_h, jitter_xy[2 * s], jitter_xy[2 * s + 1]);
+                    sample = (uint64_t)pix * (uint64_t)spp + (uint64_t)s;
+                }
+                if (cam->has_focus) {                                            // ImagePlane.depthOfFieldJitter, Image.fs:91-94; Ray.fs:15-18
+                    Rng rng(seed, sample, 0, 0, 2);
+                    Ray shifted{add(ray.o, scale(ray.d, cam->focal_length)), ray.d};             // shiftOrigin focalLength
+                    shifted.d = jitterVector(rng, 1, cam->aperture_angular_size, shifted.d)[0];  // jitterDirection
+                    ray = Ray{add(shifted.o, scale(shifted.d, -cam->focal_length)), shifted.d};  // shiftOrigin -focalLength
+                }
+                colours[(size_t)r] = getColourForRay(c, max_depth, ray, Stream{seed, sample, max_depth});   // shadeRay, Shading.fs:142
             }
         }
     };
@@ -822,11 +895,17 @@ int32_t fto_render(fto_context* c, const ft_camera* cam, int32_t res_h, int32_t 
     for (int i = 1; i < nthreads; ++i) pool.emplace_back(worker);
     worker();
     for (auto& t : pool) t.join();
-    for (size_t i = 0; i < pixels.size(); ++i) {                                 // blendPixels: Array.average, Image.fs:112-116
-        V3 acc = {0, 0, 0};
-        for (int s = 0; s < spp; ++s) acc = add(acc, colours[i * spp + s]);
+    for (size_t i = 0; i < pixels.size(); ++i) {
         double* o = out_rgb + 3 * (size_t)pixels[i];
-        o[0] = acc.x / (double)spp; o[1] = acc.y / (double)spp; o[2] = acc.z / (double)spp;  // DivideByInt, CommonTypes.fs:43
+        V3 acc = {0, 0, 0};
+        if (corner) {                                                            // Seq.average over the four corners, Image.fs:138-141
+            int x = pixels[i] % res_h, y = pixels[i] / res_h;
+            for (int id : {y * stride + x, y * stride + x + 1, (y + 1) * stride + x, (y + 1) * stride + x + 1}) acc = add(acc, colours[(size_t)cornerSlot[(size_t)id]]);
+            o[0] = acc.x / 4.0; o[1] = acc.y / 4.0; o[2] = acc.z / 4.0;
+        } else {                                                                 // blendPixels: Array.average, Image.fs:112-116
+            for (int s = 0; s < spp; ++s) acc = add(acc, colours[i * spp + s]);
+            o[0] = acc.x / (double)spp; o[1] = acc.y / (double)spp; o[2] = acc.z / (double)spp;  // DivideByInt, CommonTypes.fs:43
+        }
     }
     if (stats) {
         stats->rays_primary = (uint64_t)nRays; stats->rays_shadow = c->counters.shadow; stats->rays_reflect = c->counters.reflect;
@@ -876,7 +955,7 @@ int32_t fto_blocked(fto_context* c, const double* o, const double* d, const doub
 int32_t fto_colour_for_ray(fto_context* c, const double* o, const double* d, int64_t n, int32_t max_depth, double* rgb) {
     if (!c || !c->committed) return FT_ERR_STATE;
     for (int64_t i = 0; i < n; ++i) {
-        V3 col = getColourForRay(c, max_depth, Ray{{o[3 * i], o[3 * i + 1], o[3 * i + 2]}, {d[3 * i], d[3 * i + 1], d[3 * i + 2]}});
+        V3 col = getColourForRay(c, max_depth, Ray{{o[3 * i], o[3 * i + 1], o[3 * i + 2]}, {d[3 * i], d[3 * i + 1], d[3 * i + 2]}}, Stream{0, (uint64_t)i, max_depth});
         rgb[3 * i] = col.x; rgb[3 * i + 1] = col.y; rgb[3 * i + 2] = col.z;
     }
     return FT_OK;

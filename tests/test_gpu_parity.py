@@ -284,3 +284,52 @@ def test_textures_and_oren_nayar(hip):
     got, st = hip.render(cam, 160, 120, 2, jit)
     worst = H.assert_frames_match(got, want, what="textures + Oren-Nayar")
     assert worst < 1e-6
+
+
+STOCHASTIC = [("night-house", 160, 90, 3), ("sample-soft", 96, 96, 4), ("repeat", 160, 90, 2)]
+
+
+@pytest.mark.parametrize("name,w,h,spp", STOCHASTIC)
+def test_seeded_soft_shadows_and_depth_of_field(hip, name, w, h, spp):
+    """softdirectional lights (Shading.fs:24-31, Jitter.fs:26-39) and camera focus (Image.fs:91-94) on the seeded
+    counter-based stream: the reference is unseeded, so parity is against the oracle drawing the same stream."""
+    p = _load(name)
+    orc = O.Oracle()
+    p.lower(orc)
+    p.lower(hip)
+    jit = ft.jitter_pattern(spp)
+    want, ost = orc.render(p.camera, w, h, spp, jit, seed=1234)
+    got, st = hip.render(p.camera, w, h, spp, jit, seed=1234)
+    worst = H.assert_frames_match(got, want, what=name)
+    assert worst < 1e-6
+    assert st["rays_reference_equivalent"] == pytest.approx(ost["rays_traced"], rel=1e-12)
+    other, _ = hip.render(p.camera, w, h, spp, jit, seed=99)
+    assert not np.array_equal(other, got), "the seed does not reach the stochastic paths"
+    # streams are keyed by (pixel, sample, depth, light): tiling and chunking cannot change a pixel
+    tiled = np.zeros_like(got)
+    hip.set_option("chunk_samples", 4096)
+    hip.render(p.camera, w, h, spp, jit, seed=1234, tiles=[(0, 0, w, h // 2)], out=tiled)
+    hip.render(p.camera, w, h, spp, jit, seed=1234, tiles=[(0, h // 2, w, h - h // 2)], out=tiled)
+    hip.set_option("chunk_samples", 8 << 20)
+    assert np.array_equal(tiled, got)
+
+
+@pytest.mark.parametrize("name", ["hollow-sphere", "night-house", "sample-soft"])
+def test_corner_sampling(hip, name):
+    """`samples corner` (CornerSampling, Image.fs:125-150): spp = 0 through the ABI."""
+    p = _load(name)
+    orc = O.Oracle()
+    p.lower(orc)
+    p.lower(hip)
+    w, h = 72, 40
+    want, ost = orc.render(p.camera, w, h, 0, None, seed=5)
+    got, st = hip.render(p.camera, w, h, 0, None, seed=5)
+    H.assert_frames_match(got, want, what=name + " corner")
+    assert st["rays_primary"] == (w + 1) * (h + 1) == ost["rays_primary"]
+    part = np.full_like(got, -7.0)
+    hip.set_option("chunk_samples", 1000)                    # forces the corner grid to be split by rows
+    hip.render(p.camera, w, h, 0, None, seed=5, tiles=[(8, 4, 40, 30), (60, 0, 12, 7)], out=part)
+    hip.set_option("chunk_samples", 8 << 20)
+    mask = np.zeros((h, w), dtype=bool)
+    mask[4:34, 8:48] = True; mask[0:7, 60:72] = True
+    assert np.array_equal(part[mask], got[mask]) and (part[~mask] == -7.0).all()

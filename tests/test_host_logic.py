@@ -135,11 +135,13 @@ def test_host_only_context_never_renders():
 def test_unsupported_surface_is_rejected_loudly():
     ctx = ft.Context(host_only=True)
     ctx.clear()
-    ctx.set_objects(ctx.group([ctx.primitive(ft.SPHERE)]))
-    ctx.add_soft_directional((0, -1, 0), 4, 0.1, (1, 1, 1))
+    ops = [(0, 0.5, 0.5)] * 6                                # six nested texture functions: beyond the device path's fixed table
+    ctx.set_objects(ctx.group([ctx.texture_grid((1, 0, 0), (0, 1, 0), ops, ctx.primitive(ft.SPHERE))]))
     with pytest.raises(ft.FtError) as e:
         ctx.commit()
-    assert e.value.status == -4 and "softdirectional" in str(e.value)
+    assert e.value.status == -4 and "texture" in str(e.value)
+    with pytest.raises(ft.FtError):                           # image textures need files / HTTP: refused by the lowering (FT_ERR_UNSUPPORTED)
+        ft.parse_scene('(texture image "x.jpg" sphere)\n').lower(ctx)
     with pytest.raises(ft.FtError):
         ctx.primitive(99)
     with pytest.raises(ft.FtError):
