@@ -5,6 +5,10 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+Scaling is WEAK: the path shards into independent samples, so N ranks render a frame with N times the
+samples per pixel (1920x1080 x 16*N spp; N = 1 is exactly the BASELINE configuration) and every rank keeps the
+per-GPU work of the single-GPU run.  `--strong` keeps the frame fixed at 16 spp instead.
+
 A step = one full frame: every rank renders its interleaved 8-row bands of the frame through the
 C ABI with the frame left in HBM (out_rgb = NULL); scene, jitter pattern and pixel lists are
 HBM-resident before the timed region.  The K steps are bracketed by barrier + device synchronise
@@ -37,6 +41,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true", help="keep the frame fixed as ranks are added (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,7 +70,8 @@ def main():
 
     scene = ft.parse_scene_file(os.path.join(ROOT, "scenes", args.scene + ".scene"))
     res_h, res_v = args.res if args.res else scene.resolution
-    spp = args.spp if args.spp else scene.samples
+    base_spp = args.spp if args.spp else scene.samples
+    spp = base_spp if args.strong else base_spp * world          # weak scaling: per-GPU samples stay those of the N = 1 run
     jitter = ft.jitter_pattern(spp)
     ctx = ft.Context(device=local_rank)
     scene.lower(ctx)
@@ -138,11 +144,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(wall_max / steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"scenes/{args.scene}.scene {res_h}x{res_v}x{spp}spp, depth 8, synthetic bunny stand-in mesh (980 tris), seeded jitter",
+            "config": {"workload": f"scenes/{args.scene}.scene {res_h}x{res_v}x{spp}spp ({base_spp} spp per GPU-share), depth 8, synthetic stand-in mesh, seeded jitter",
                        "parallelism": f"image-tiled, {world} rank(s) x interleaved {tiling.BAND_ROWS}-row bands, no collective on the data path"},
             "kernel_ms_per_step": round(kernel_ms_max / steps, 4),
             "value_kernel_only": round(mrays_kernel, 3),
@@ -154,9 +160,16 @@ def main():
                          "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_ray": ALGO_BYTES_PER_RAY},
             "per_kernel_ms_per_step": {k: round(v / steps, 4) for k, v in k_times.items()},
         }
+        traffic_file = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.scene}.json")
+        if os.path.exists(traffic_file) and world == 1 and not args.res and not args.spp:
+            with open(traffic_file) as f:
+                t = json.load(f).get("k_" + dom)
+            if t:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command
+                out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"])
+                out["roofline"]["traffic_source"] = os.path.relpath(traffic_file, ROOT)
         out["rays_per_frame"] = {"traced_rank0": int(rays_rank), "traced_all_ranks": int(rays_total / steps),
                                  "reference_equivalent_rank0": st["rays_reference_equivalent"]}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, res_h, res_v, spp, jitter, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -175,7 +188,7 @@ def cpu_baseline(scene, res_h, res_v, spp, jitter, budget_s):
     orc = O.Oracle()
     scene.lower(orc)
     cores = os.cpu_count() or 1
-    # calibrate on a thin sample, then size the real sample to ~budget_s
+    # (always the N = 1 workload's spp) calibrate on a thin sample, then size the real sample to ~budget_s
     probe = tiling.bands_for_rank(res_h, res_v, 0, 64)
     frame = np.zeros((res_v, res_h, 3))
     _, st = orc.render(scene.camera, res_h, res_v, spp, jitter, tiles=probe, threads=cores, out=frame)

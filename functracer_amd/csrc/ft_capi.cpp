@@ -444,21 +444,23 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
     c->events_used = 0;
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
-    auto timed = [&](int kind, auto&& fn) {
-        hipEvent_t a = next_event(c), b = next_event(c);
-        if (a) (void)hipEventRecord(a, c->stream);
-        fn();
-        if (b) (void)hipEventRecord(b, c->stream);
-        if (a && b) spans.push_back({a, b, kind});
-    };
-    hipEvent_t ev0 = next_event(c), ev1 = next_event(c);
+    // One event per stage boundary (the end of a stage is the start of the next): half the markers of a pair per stage.
+    hipEvent_t ev0 = next_event(c), ev1 = nullptr;
     if (ev0) (void)hipEventRecord(ev0, c->stream);
+    hipEvent_t boundary = ev0;
+    auto timed = [&](int kind, auto&& fn) {
+        fn();
+        hipEvent_t b = next_event(c);
+        if (b) (void)hipEventRecord(b, c->stream);
+        if (boundary && b) spans.push_back({boundary, b, kind});
+        boundary = b;
+    };
     int n_chunks = 0, n_launches = 0;
     for (const Job& job : jobs) {
         ++n_chunks;
         const uint32_t n_pix = job.n_ids;
         const uint32_t n_samples = n_pix * (uint32_t)spp;
-        FT_HIP(c, hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream));
+        timed(0, [&] { (void)hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream); });
         const ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
                                (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed};
         timed(0, [&] { (void)hipMemsetAsync(c->d_acc.p, 0, (size_t)n_samples * 24, c->stream); });   // accumulators start at Colour.Zero
@@ -474,7 +476,7 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
         else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, out_index, out_ptr); });
         ++n_launches;
     }
-    if (ev1) (void)hipEventRecord(ev1, c->stream);
+    ev1 = boundary;
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipStreamSynchronize(c->stream));
 

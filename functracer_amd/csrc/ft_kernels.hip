@@ -665,11 +665,19 @@ FT_DEV uint32_t unit_batches_for(uint32_t n) {
     uint32_t u = n / (64u * waves * 4u);                            // aim at >= 4 units per wave
     return u < 1u ? 1u : (u > 16u ? 16u : u);
 }
-FT_DEV uint32_t grab_unit(uint32_t* cursor, uint32_t rays) {
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(cursor, rays);
-    return __builtin_amdgcn_readfirstlane(base);
-}
+// The first unit of every wave is static (unit = global wave id: no atomic, so an empty or tiny launch costs no
+// traffic on the counter word at all); later units come from the cursor, which counts units beyond those.
+struct UnitCursor {
+    uint32_t* cursor; uint32_t rays_per_unit; bool first;
+    FT_DEV UnitCursor(uint32_t* c, uint32_t rays) : cursor(c), rays_per_unit(rays), first(true) {}
+    FT_DEV uint32_t next() {
+        const uint32_t waves = gridDim.x * (kBlock / 64);
+        if (first) { first = false; return (blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * rays_per_unit; }
+        uint32_t u = 0;
+        if (lane_id() == 0) u = atomicAdd(cursor, 1u);
+        return (__builtin_amdgcn_readfirstlane(u) + waves) * rays_per_unit;
+    }
+};
 
 FT_DEV void wave_add(unsigned long long* dst, unsigned long long v_per_lane_flag_count) {
     // caller passes an already wave-reduced value from lane 0 only
@@ -743,8 +751,9 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, Ra
     const uint32_t n = bounce == 0 ? gen.n_pix * (uint32_t)gen.spp : cc->n_rays[bounce];
     const uint32_t unit = unit_batches_for(n);
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
+    UnitCursor units(&cc->work_trace[bounce], unit * 64u);
     for (;;) {
-        const uint32_t ubase = grab_unit(&cc->work_trace[bounce], unit * 64u);
+        const uint32_t ubase = units.next();
         if (ubase >= n) break;
         uint32_t mask_lo = 0, mask_hi = 0, unit_hits = 0;          // lane b keeps the hit mask of batch b of this unit
         for (uint32_t b = 0; b < unit; ++b) {
@@ -798,8 +807,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
     const int n_lights = S.n_lights;
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
     const uint32_t unit = unit_batches_for(n);
+    UnitCursor units(&cc->work_shade[bounce], unit * 64u);
     for (uint32_t ub = 0, ubase = 0;; ++ub) {
-        if (ub % unit == 0) ubase = grab_unit(&cc->work_shade[bounce], unit * 64u);
+        if (ub % unit == 0) ubase = units.next();
         const uint32_t base = ubase + (ub % unit) * 64u;
         if (base >= n) { if (ub % unit == 0) break; ub += unit - 1 - (ub % unit); continue; }
         const uint32_t j = base + lane_id();
