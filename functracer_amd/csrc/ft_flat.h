@@ -106,8 +106,10 @@ enum Op : uint32_t {
     OP_MARK = 3,           // push the current list length (start of an operand segment)
     OP_CSG = 4,            // merge the two topmost segments with rule table arg (ft_csg_op)
     OP_FOLD_LIST = 5,      // fold the per-lane list into closest / any-hit and clear it
-    OP_CULL = 6            // arg = cull record; next word = number of program words of the item that follows.
+    OP_CULL = 6,           // arg = cull record; next word = number of program words of the item that follows.
                            // If no lane of the wave can possibly hit the item, the item is skipped.
+    OP_SKIP_IF_EMPTY = 7   // after operand A of subtract / intersect: if no lane has an A hit the result is empty for
+                           // every lane (Csg.fs:27-44 never Take/Flip a B hit while outside A), so pop A's mark and skip arg words
 };
 
 // Conservative bound of one top-level item (a leaf or an outermost CSG subtree), 24 doubles.
@@ -123,8 +125,8 @@ struct CullRecord {
 };
 inline uint32_t make_op(uint32_t op, uint32_t arg) { return op | (arg << 8); }
 
-// Hit identity: id0 = leaf | sub << 24 | flip << 30 | sideB << 31 (sideB only while sorting); id1 = triangle index.
-enum : uint32_t { ID_LEAF_MASK = 0x00FFFFFFu, ID_SUB_SHIFT = 24, ID_SUB_MASK = 0x7u, ID_FLIP = 1u << 30, ID_SIDE_B = 1u << 31, ID_MISS = 0xFFFFFFFFu };
+// Hit identity: id0 = leaf | sub << 24 | lit << 29 | flip << 30 | sideB << 31 (sideB only while sorting); id1 = triangle index.
+enum : uint32_t { ID_LEAF_MASK = 0x00FFFFFFu, ID_SUB_SHIFT = 24, ID_SUB_MASK = 0x7u, ID_LIT = 1u << 29, ID_FLIP = 1u << 30, ID_SIDE_B = 1u << 31, ID_MISS = 0xFFFFFFFFu };
 
 } // namespace ftd
 #endif

@@ -530,7 +530,8 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
             }
             case OP_LEAF_PUSH: {
                 const LeafHead H = leaf_head(S, arg);
-                leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { if (q.active) L.push(t, arg | (sub << ID_SUB_SHIFT), tri); });
+                const uint32_t tag = arg | ((H.flags & LF_LIT) ? ID_LIT : 0u);
+                leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { if (q.active) L.push(t, tag | (sub << ID_SUB_SHIFT), tri); });
                 break;
             }
             case OP_CULL: {
@@ -551,11 +552,17 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
             }
             case OP_MARK: L.mark(); break;
             case OP_CSG: csg_merge(L, arg); break;
+            case OP_SKIP_IF_EMPTY: {
+                const int seg_a = (int)(L.marks_lo & 0xFF);
+                if (!__any(q.active && L.len > seg_a)) { L.pop_mark(); pc += arg; }
+                break;
+            }
             default: {                                             // OP_FOLD_LIST
-                for (int e = 0; e < L.len; ++e) {
-                    const uint32_t id0 = L.id0_of(e);
-                    const LeafHead H = leaf_head(S, id0 & ID_LEAF_MASK);   // per-lane leaf: vector load
-                    q.hit(L.t_of(e), id0, L.id1_of(e), (H.flags & LF_LIT) != 0);
+                if (__any(L.len > 0)) {
+                    for (int e = 0; e < L.len; ++e) {
+                        const uint32_t id0 = L.id0_of(e);
+                        q.hit(L.t_of(e), id0, L.id1_of(e), (id0 & ID_LIT) != 0);
+                    }
                 }
                 L.len = 0;
                 break;

@@ -313,9 +313,13 @@ struct Flattener {
                 ItemMark im = begin_item(in_csg);
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
                 walk(n.children[0], c, true);
+                const bool a_gates = n.op == FT_CSG_SUBTRACT || n.op == FT_CSG_INTERSECT;   // no A hit => empty result
+                const size_t skip_at = out.program.size();
+                if (a_gates) out.program.push_back(ftd::make_op(ftd::OP_SKIP_IF_EMPTY, 0));
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
                 walk(n.children[1], c, true);
                 out.program.push_back(ftd::make_op(ftd::OP_CSG, (uint32_t)n.op));
+                if (a_gates) out.program[skip_at] = ftd::make_op(ftd::OP_SKIP_IF_EMPTY, (uint32_t)(out.program.size() - skip_at - 1));
                 --csg_depth;
                 if (!in_csg) { out.program.push_back(ftd::make_op(ftd::OP_FOLD_LIST, 0)); cur_list = before; }
                 end_item(im);
