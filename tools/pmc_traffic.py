@@ -22,7 +22,7 @@ def load(directory, counter):
         with open(path) as f:
             for r in csv.DictReader(f):
                 if r["Counter_Name"] == counter:
-                    m = re.search(r"\b(k_\w+)\(", r["Kernel_Name"])
+                    m = re.search(r"\b(k_\w+)[<(]", r["Kernel_Name"])
                     name = m.group(1) if m else r["Kernel_Name"].split("(")[0]
                     rows[name].append(float(r["Counter_Value"]) * 1024.0)
     return rows
