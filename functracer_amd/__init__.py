@@ -168,8 +168,9 @@ class Context(SceneBuilder):
         if host_only:
             rc = lib.ft_create_host_only(C.byref(h))
         else:
-            dev = (C.c_int32 * 1)(int(device))
-            rc = lib.ft_create(dev, 1, C.byref(h))
+            ids = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+            dev = (C.c_int32 * len(ids))(*ids)                # several ids: one context that tiles every frame over those GPUs
+            rc = lib.ft_create(dev, len(ids), C.byref(h))
         if rc < 0:
             raise FtError(rc, "ft_create: no usable HIP device (the HIP path has no CPU fallback)" if rc == -2 else "ft_create")
         self.device = device

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/functracer_hip.h"
@@ -25,6 +26,7 @@ struct DeviceBuf {
 };
 
 struct ft_context {
+    std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
     bool host_only = false;
     int device = -1;
     int n_cu = 0;
@@ -144,20 +146,35 @@ extern "C" {
 
 int32_t ft_abi_version(void) { return FT_ABI_VERSION; }
 
-int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out) {
-    if (!out) return FT_ERR_INVALID;
-    *out = nullptr;
-    if (n_devices < 1 || !device_ids) return FT_ERR_NO_DEVICE;     // no CPU backend exists in this library
-    if (n_devices > 1) return FT_ERR_UNSUPPORTED;                  // one context per device; frames are tiled across contexts/processes
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return FT_ERR_NO_DEVICE;
-    if (device_ids[0] < 0 || device_ids[0] >= count) return FT_ERR_INVALID;
+static int32_t create_single(int32_t device_id, int count, ft_context** out) {
+    if (device_id < 0 || device_id >= count) return FT_ERR_INVALID;
     ft_context* c = new ft_context();
-    c->device = device_ids[0];
+    c->device = device_id;
     hipDeviceProp_t prop;
     if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FT_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return FT_OK;
+}
+
+int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out) {
+    if (!out) return FT_ERR_INVALID;
+    *out = nullptr;
+    if (n_devices < 1 || !device_ids) return FT_ERR_NO_DEVICE;     // no CPU backend exists in this library
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return FT_ERR_NO_DEVICE;
+    ft_context* c = nullptr;
+    int32_t rc = create_single(device_ids[0], count, &c);
+    if (rc != FT_OK) return rc;
+    // More devices: the scene is replicated and every frame is split into 8-row bands dealt round-robin (no exchange
+    // between devices; the bands meet in the caller's host buffer).  The same ordinal may be listed twice.
+    for (int32_t k = 1; k < n_devices; ++k) {
+        ft_context* p = nullptr;
+        rc = create_single(device_ids[k], count, &p);
+        if (rc != FT_OK) { ft_destroy(c); return rc; }
+        c->peers.push_back(p);
+    }
     *out = c;
     return FT_OK;
 }
@@ -172,6 +189,8 @@ int32_t ft_create_host_only(ft_context** out) {
 
 void ft_destroy(ft_context* c) {
     if (!c) return;
+    for (ft_context* p : c->peers) ft_destroy(p);
+    c->peers.clear();
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -189,7 +208,7 @@ const char* ft_last_error(const ft_context* c) { return c ? c->err.c_str() : "nu
 
 int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!c || !key) return FT_ERR_INVALID;
-    if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; return FT_OK; }
+    if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; for (ft_context* p : c->peers) p->chunk_samples = value; return FT_OK; }
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
     return FT_ERR_INVALID;
@@ -283,11 +302,23 @@ int32_t ft_scene_add_positional(ft_context* c, const double pos[3], const double
     return FT_OK;
 }
 
+static int32_t upload_scene(ft_context* c);
+
 int32_t ft_scene_commit(ft_context* c) {
     if (!c) return FT_ERR_INVALID;
     int32_t rc = c->graph.flatten(c->flat, c->err);
     if (rc != FT_OK) return rc;
     if (c->host_only) { c->committed = true; return FT_OK; }
+    if ((rc = upload_scene(c)) != FT_OK) return rc;
+    for (ft_context* p : c->peers) {                                // replicate the flattened scene on every other device
+        p->flat = c->flat;
+        if ((rc = upload_scene(p)) != FT_OK) { c->err = p->err; return rc; }
+    }
+    return FT_OK;
+}
+
+static int32_t upload_scene(ft_context* c) {
+    int32_t rc;
     FT_HIP(c, hipSetDevice(c->device));
     const fth::FlatScene& f = c->flat;
     if (lds_bytes_for(f) > 160 * 1024) { c->err = "scene needs more than 160 KiB of LDS per workgroup for CSG lists / BSP stacks"; return FT_ERR_UNSUPPORTED; }
@@ -320,9 +351,24 @@ int32_t ft_scene_commit(ft_context* c) {
 }
 
 // Copy the pixels of the last ft_render from HBM into the caller's frame (row 0 = top, Image.fs:39).
+static int32_t fetch_single(ft_context* c, double* out_rgb);
+
 int32_t ft_fetch_frame(ft_context* c, double* out_rgb) {
     if (!c || !out_rgb) return FT_ERR_INVALID;
     if (!need_device(c)) return FT_ERR_NO_DEVICE;
+    bool any = false;
+    int32_t rc = FT_OK;
+    if (c->last_n_pix > 0) { rc = fetch_single(c, out_rgb); any = true; }
+    for (ft_context* p : c->peers) {                                // every device copies its own bands into the caller's frame
+        if (rc != FT_OK || p->last_n_pix <= 0) continue;
+        rc = fetch_single(p, out_rgb); any = true;
+        if (rc != FT_OK) c->err = p->err;
+    }
+    if (!any) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
+    return rc;
+}
+
+static int32_t fetch_single(ft_context* c, double* out_rgb) {
     if (c->last_n_pix <= 0) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
     FT_HIP(c, hipSetDevice(c->device));
     const int64_t n = c->last_n_pix;
@@ -337,8 +383,53 @@ int32_t ft_fetch_frame(ft_context* c, double* out_rgb) {
 }
 
 // ------------------------------------------------------------------------------------------ render
+static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats);
+
 int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                   int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
+    if (!c) return FT_ERR_INVALID;
+    if (c->peers.empty() || c->host_only) return render_single(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats);
+    if (!cam || res_h < 2 || res_v < 2 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
+    if (!c->committed) { c->err = "scene not committed (ft_scene_commit)"; return FT_ERR_STATE; }
+    // Image-tile partition over the devices: 8-row bands of every requested rect, dealt round-robin.
+    const auto wall0 = std::chrono::steady_clock::now();
+    std::vector<ft_context*> devs{c};
+    devs.insert(devs.end(), c->peers.begin(), c->peers.end());
+    std::vector<std::vector<ft_rect>> share(devs.size());
+    std::vector<ft_rect> whole_frame{ft_rect{0, 0, res_h, res_v}};
+    const ft_rect* src = tiles ? tiles : whole_frame.data();
+    const int n_src = tiles ? n_tiles : 1;
+    size_t band = 0;
+    for (int k = 0; k < n_src; ++k)
+        for (int y = src[k].y0; y < src[k].y0 + src[k].h; y += 8, ++band)
+            share[band % devs.size()].push_back(ft_rect{src[k].x0, y, src[k].w, std::min(8, src[k].y0 + src[k].h - y)});
+    std::vector<int32_t> rcs(devs.size(), FT_OK);
+    std::vector<ft_stats> sts(devs.size());
+    std::vector<std::thread> threads;
+    for (size_t d = 0; d < devs.size(); ++d)
+        threads.emplace_back([&, d] {
+            std::memset(&sts[d], 0, sizeof(ft_stats));
+            if (share[d].empty()) { devs[d]->last_n_pix = 0; return; }
+            rcs[d] = render_single(devs[d], cam, res_h, res_v, spp, jitter_xy, max_depth, seed, share[d].data(), (int32_t)share[d].size(), out_rgb, &sts[d]);
+        });
+    for (auto& t : threads) t.join();
+    for (size_t d = 0; d < devs.size(); ++d) if (rcs[d] != FT_OK) { if (d) c->err = devs[d]->err; return rcs[d]; }
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (auto& s : sts) {
+            stats->rays_primary += s.rays_primary; stats->rays_shadow += s.rays_shadow; stats->rays_reflect += s.rays_reflect; stats->rays_traced += s.rays_traced;
+            stats->rays_reference_equivalent += s.rays_reference_equivalent; stats->hits_primary += s.hits_primary; stats->csg_overflow += s.csg_overflow;
+            stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms); stats->trace_kernel_ms = std::max(stats->trace_kernel_ms, s.trace_kernel_ms);
+            stats->algorithmic_bytes += s.algorithmic_bytes; stats->n_launches += s.n_launches; stats->n_chunks += s.n_chunks;
+        }
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    return FT_OK;
+}
+
+static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
     if (!c) return FT_ERR_INVALID;
     if (!cam || res_h < 2 || res_v < 2 || spp < 0 || (spp > 0 && !jitter_xy) || max_depth < 0 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
     if (max_depth > ftk::kMaxBounce) { c->err = "max_depth above 16"; return FT_ERR_UNSUPPORTED; }
@@ -483,7 +574,7 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
     ftk::RenderCounters hrc{};
     FT_HIP(c, hipMemcpy(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost));
     c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v;
-    if (out_rgb) { int32_t frc = ft_fetch_frame(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
+    if (out_rgb) { int32_t frc = fetch_single(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
     for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
     for (auto& s : spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; } }
     if (stats) {

@@ -123,7 +123,9 @@ typedef struct ft_stats {
 
 /* ---- context ---------------------------------------------------------------------------- */
 int32_t ft_abi_version(void);
-/* device_ids: HIP device ordinals; n_devices must be >= 1 (0 ⇒ FT_ERR_NO_DEVICE: no CPU path). */
+/* device_ids: HIP device ordinals; n_devices must be >= 1 (0 ⇒ FT_ERR_NO_DEVICE: no CPU path).  With several
+ * ordinals the scene is replicated on each device and every ft_render splits its region into 8-row bands dealt
+ * round-robin over them, one host thread per device, no exchange between devices (bands meet in out_rgb). */
 int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out);
 void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);

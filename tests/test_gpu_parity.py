@@ -333,3 +333,24 @@ def test_corner_sampling(hip, name):
     mask = np.zeros((h, w), dtype=bool)
     mask[4:34, 8:48] = True; mask[0:7, 60:72] = True
     assert np.array_equal(part[mask], got[mask]) and (part[~mask] == -7.0).all()
+
+
+def test_multi_device_context_equals_single_device(hip):
+    """ft_create with several device ordinals: the scene is replicated and frames are band-partitioned inside the
+    library.  With one GPU on the test box the same ordinal is listed three times (three sub-contexts)."""
+    p = _load("night-house")
+    p.lower(hip)
+    multi = ft.Context(device=[0, 0, 0])
+    p.lower(multi)
+    jit = ft.jitter_pattern(2)
+    want, st1 = hip.render(p.camera, 320, 180, 2, jit, seed=3)
+    got, st3 = multi.render(p.camera, 320, 180, 2, jit, seed=3)
+    assert np.array_equal(got, want)
+    assert st3["rays_traced"] == st1["rays_traced"] and st3["rays_primary"] == 320 * 180 * 2
+    _, _ = multi.render(p.camera, 320, 180, 2, jit, seed=3, fetch=False)       # frame left in HBM on every device
+    later = multi.fetch_frame(np.zeros_like(want))
+    assert np.array_equal(later, want)
+    part = np.full_like(want, -1.0)
+    multi.render(p.camera, 320, 180, 2, jit, seed=3, tiles=[(16, 8, 64, 40)], out=part)
+    assert np.array_equal(part[8:48, 16:80], want[8:48, 16:80]) and (part[:8] == -1.0).all()
+    multi.close()
