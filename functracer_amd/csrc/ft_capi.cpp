@@ -16,7 +16,7 @@
 #include "ft_scene.h"
 
 namespace ftk {
-int occupancy_blocks_closest(size_t lds_bytes);
+int occupancy_blocks_closest(size_t lds_bytes, int variant);
 int occupancy_blocks_shade(size_t lds_bytes, int variant);
 }
 
@@ -520,9 +520,10 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
     int variant = 0;
-    for (auto& m : c->flat.materials) { if (m.roughness != 0.0) variant |= 1; if (m.texture >= 0) variant |= 2; }
-    for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 4;
-    ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds), lds, 0};
+    for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;   // FANCY
+    for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
+    if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
+    ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds, variant), lds, variant};
     ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds, variant), lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
     const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned

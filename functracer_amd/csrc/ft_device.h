@@ -61,7 +61,7 @@ struct Launch {
     hipStream_t stream;
     int grid;                      // persistent grid size (workgroups)
     size_t lds_bytes;
-    int variant;                   // k_shade: bit 0 = Oren-Nayar, bit 1 = textures, bit 2 = soft lights compiled in
+    int variant;                   // kernel variant: bit 0 = Oren-Nayar / textures, bit 1 = soft lights, bit 2 = meshes compiled in
 };
 
 // Everything bounce 0 needs to regenerate a primary ray from its sample index i = s*n_pix + pixel.

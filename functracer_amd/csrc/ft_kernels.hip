@@ -298,7 +298,7 @@ FT_DEV bool quadratic(double a, double b, double c, double& r0, double& r1) {
     return true;
 }
 
-template <class Emit>
+template <bool MESH, class Emit>
 FT_DEV void leaf_hits(const Scene& S, uint32_t leaf, const LeafHead& H, const Ray& rw, bool active, int32_t* stack, Emit&& emit) {
     Ray r;
     to_model(S.leaves + 16ull * leaf, (H.flags & LF_XFORM) != 0, rw, r);
@@ -386,7 +386,7 @@ FT_DEV void leaf_hits(const Scene& S, uint32_t leaf, const LeafHead& H, const Ra
             break;
         }
         default:                                                   // LK_MESH
-            mesh_hits(S, H.mesh, r, active, stack, emit);
+            if (MESH) mesh_hits(S, H.mesh, r, active, stack, emit);
             break;
     }
 }
@@ -501,7 +501,9 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t bvh_root, const Ray& r, Quer
 
 // ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
-template <bool ANY>
+// MESH = false compiles the triangle / BSP / BVH code out: scenes without meshes then run kernels with
+// markedly fewer registers (k_closest 123 -> 92 VGPRs, 4 -> 5 waves per SIMD).
+template <bool ANY, bool MESH>
 FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow, bool coherent = false) {
     HitList L;
     L.init(lds, S.csg_cap);
@@ -515,7 +517,7 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                 const LeafHead H = leaf_head(S, arg);
                 const bool lit = (H.flags & LF_LIT) != 0;
                 if (ANY && !lit) break;                            // an unlit object never blocks light (Scene.fs:121)
-                if (H.kind == LK_MESH) {
+                if (MESH && H.kind == LK_MESH) {
                     const int32_t bvh = S.meshes[4 * H.mesh + 3];
                     if (bvh >= 0) {
                         Ray rm;
@@ -525,13 +527,13 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                         break;
                     }
                 }
-                leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { q.hit(t, arg | (sub << ID_SUB_SHIFT), tri, lit); });
+                leaf_hits<MESH>(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { q.hit(t, arg | (sub << ID_SUB_SHIFT), tri, lit); });
                 break;
             }
             case OP_LEAF_PUSH: {
                 const LeafHead H = leaf_head(S, arg);
                 const uint32_t tag = arg | ((H.flags & LF_LIT) ? ID_LIT : 0u);
-                leaf_hits(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { if (q.active) L.push(t, tag | (sub << ID_SUB_SHIFT), tri); });
+                leaf_hits<MESH>(S, arg, H, r, q.active, stack, [&](double t, uint32_t sub, uint32_t tri) { if (q.active) L.push(t, tag | (sub << ID_SUB_SHIFT), tri); });
                 break;
             }
             case OP_CULL: {
@@ -751,7 +753,8 @@ FT_DEV Ray primary_ray(const Primary& g, uint32_t i) {
     return r;
 }
 
-__global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
+template <bool MESH>
+__global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
                                                      ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, Ra
                 r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
             }
             bool overflow;
-            trace<false>(S, r, q, lds, overflow, bounce == 0);    // primary rays of one pixel block walk meshes as a packet
+            trace<false, MESH>(S, r, q, lds, overflow, bounce == 0);   // primary rays of one pixel block walk meshes as a packet
             const bool hit = q.active && q.id0 != ID_MISS;
             if (q.active) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }
             const unsigned long long m = __ballot(hit);
@@ -802,16 +805,20 @@ __global__ __launch_bounds__(kBlock) void k_closest(DevScene Sg, Primary gen, Ra
     wave_add(&rc->csg_overflow, n_ovf_wave);
 }
 
-// ROUGH / TEXTURED select the variants with Oren-Nayar and grid textures compiled in: they need libm-heavy
-// code (acos, tan, atan2 ...) whose registers would otherwise halve the occupancy of every scene.
-template <bool ROUGH, bool TEXTURED, bool SOFT>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
+// k_shade variants: FANCY = Oren-Nayar and grid textures compiled in (libm-heavy code: acos, tan, atan2 ...),
+// SOFT = softdirectional lights, MESH = triangle meshes.  Scenes that lack a feature run a leaner kernel.
+//
+// Two passes over the lights keep the live state across the shadow traces small (p, n and a few words instead
+// of the whole fragment state): pass 1 only decides visibility (one byte per light: occluded sample count),
+// pass 2 reloads the ray and the material and evaluates the shaders.
+template <bool FANCY, bool SOFT, bool MESH>
+__global__ __launch_bounds__(kBlock, FANCY ? 1 : 3) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
                                                    double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
                                                    ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
     const uint32_t n = cc->n_hits[bounce];
-    const int n_lights = S.n_lights;
+    const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
     const uint32_t unit = unit_batches_for(n);
     UnitCursor units(&cc->work_shade[bounce], unit * 64u);
@@ -821,103 +828,126 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
         if (base >= n) { if (ub % unit == 0) break; ub += unit - 1 - (ub % unit); continue; }
         const uint32_t j = base + lane_id();
         const bool active = j < n;
-        Ray r{0, 0, 0, 0, 0, 0};
-        double w = 0.0, t = 0.0; uint32_t slot = 0, id0 = 0, id1 = 0;
+        // ---------------- pass 1: surface point + visibility of every light -------------------------------
+        Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
+        bool lit = false;
+        unsigned long long sample = 0ull;
         if (active) {
             const uint32_t i = hit_list[j];
-            if (bounce == 0) { r = primary_ray(gen, i); w = 1.0; slot = i; }
-            else { r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i]; }
-            t = hits.t[i]; id0 = hits.id0[i]; id1 = hits.id1[i];
+            Ray r;
+            uint32_t slot;
+            if (bounce == 0) { r = primary_ray(gen, i); slot = i; }
+            else { r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; slot = rays.slot[i]; }
+            // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
+            const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
+            sf = surface_at<FANCY>(S, ro, hits.t[i], hits.id0[i], hits.id1[i]);
+            lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
+            if (SOFT) sample = sample_id(gen, slot);
         }
-        // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
-        const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
-        Surface sf{{0, 0, 0}, {0, 1, 0}, 0};
-        if (active) sf = surface_at<TEXTURED>(S, ro, t, id0, id1);
-        MaterialV mat = material_at(S, sf.material);                  // per-lane gather (64 B records, L1/L2 resident)
-        if (TEXTURED) { if (active && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }   // Ray.textureDiffuse (Ray.fs:57-59)
-        const bool lit = active && mat.apply_lighting != 0;
-        double cr = 0.0, cg = 0.0, cb = 0.0;                       // sum over fragments (Seq.sumBy shader, Shading.fs:139)
-        // getLightsOnPoint (Shading.fs:109-117)
-        const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
-        for (int l = 0; l < n_lights; ++l) {                       // wave-uniform
-            cdp lp = S.lights + 12ull * (uint32_t)l;                 // wave-uniform: scalar loads
-            struct { double v[3], falloff[3], colour[3]; uint32_t kind; int32_t samples; double tan_half_scatter; } lt =
-                {{lp[0], lp[1], lp[2]}, {lp[3], lp[4], lp[5]}, {lp[6], lp[7], lp[8]}, reinterpret_cast<cup>(lp + 10)[0], reinterpret_cast<cip>(lp + 10)[1], lp[11]};
-            if (active && !lit) { cr += mat.colour[0]; cg += mat.colour[1]; cb += mat.colour[2]; }   // shadeIfRequired (Shading.fs:100-104)
-            Query<true> q;
-            q.active = lit; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0;
-            Ray sr; double intensity = 1.0; V3 ld;
-            if (lt.kind == LT_POINT) {                             // shadowLightIntensity / lightDirection (Shading.fs:33-48)
-                const double ddx = lt.v[0] - sox, ddy = lt.v[1] - soy, ddz = lt.v[2] - soz;
-                const double dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
-                const V3 dn = normalise(V3{ddx, ddy, ddz});
-                sr = {sox, soy, soz, dn.x, dn.y, dn.z};
-                q.max_dist = dist;
-                intensity = 1.0 / (lt.falloff[0] + dist * (lt.falloff[1] + dist * lt.falloff[2]));   // Light.attenuate (Light.fs:16-17)
-                ld = normalise(V3{sf.p.x - lt.v[0], sf.p.y - lt.v[1], sf.p.z - lt.v[2]});
-            } else {
-                sr = {sox, soy, soz, -lt.v[0], -lt.v[1], -lt.v[2]};
-                q.max_dist = 1.7976931348623157e308;               // System.Double.MaxValue
-                ld = {lt.v[0], lt.v[1], lt.v[2]};
-            }
+        unsigned long long vis_lo = 0ull, vis_hi = 0ull;           // byte l = occluded shadow samples of light l
+        for (int l = 0; l < n_lights; ++l) {                       // wave-uniform; getLightsOnPoint (Shading.fs:109-117)
+            cdp lp = S.lights + 12ull * (uint32_t)l;               // scalar loads
+            const uint32_t kind = reinterpret_cast<cup>(lp + 10)[0];
+            const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
+            unsigned long long occluded = 0ull;
             bool overflow = false;
-            if (SOFT && lt.kind == LT_SOFT) {                      // softShadowLightIntensity (Shading.fs:24-31)
-                const JitterFrame frame(V3{-lt.v[0], -lt.v[1], -lt.v[2]}, lt.tan_half_scatter);
-                Rng rng = make_rng(gen.seed, active ? sample_id(gen, slot) : 0ull, (uint32_t)bounce, (uint32_t)l, 1u);
-                int occluded = 0;
-                for (int k = 0; k < lt.samples; ++k) {             // wave-uniform count; each lane draws its own direction
+            if (SOFT && kind == LT_SOFT) {                         // softShadowLightIntensity (Shading.fs:24-31)
+                const int samples = reinterpret_cast<cip>(lp + 10)[1];
+                const JitterFrame frame(V3{-lp[0], -lp[1], -lp[2]}, lp[11]);
+                Rng rng = make_rng(gen.seed, sample, (uint32_t)bounce, (uint32_t)l, 1u);
+                for (int k = 0; k < samples; ++k) {                // wave-uniform count; each lane draws its own direction
                     const V3 dj = frame.jittered(rng);
                     Query<true> qs;
                     qs.active = lit; qs.blocked = false; qs.best_t = 0; qs.id0 = 0; qs.id1 = 0; qs.max_dist = 1.7976931348623157e308;
                     bool ovf = false;
-                    if (__any(lit)) trace<true>(S, Ray{sox, soy, soz, dj.x, dj.y, dj.z}, qs, lds, ovf, false);
+                    if (__any(lit)) trace<true, MESH>(S, Ray{sox, soy, soz, dj.x, dj.y, dj.z}, qs, lds, ovf, false);
                     if (qs.blocked) ++occluded;
                     overflow = overflow || ovf;
                     n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
                 }
-                intensity = (double)(lt.samples - occluded) / (double)lt.samples;
             } else {
-                if (__any(lit)) trace<true>(S, sr, q, lds, overflow, bounce == 0);
+                Query<true> q;
+                q.active = lit; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0;
+                Ray sr;
+                if (kind == LT_POINT) {                            // shadowLightIntensity (Shading.fs:33-42)
+                    const double ddx = lp[0] - sox, ddy = lp[1] - soy, ddz = lp[2] - soz;
+                    q.max_dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+                    const V3 dn = normalise(V3{ddx, ddy, ddz});
+                    sr = {sox, soy, soz, dn.x, dn.y, dn.z};
+                } else {
+                    sr = {sox, soy, soz, -lp[0], -lp[1], -lp[2]};
+                    q.max_dist = 1.7976931348623157e308;           // System.Double.MaxValue
+                }
+                if (__any(lit)) trace<true, MESH>(S, sr, q, lds, overflow, bounce == 0);
                 n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
+                occluded = q.blocked ? 1ull : 0ull;
             }
             n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && lit));
-            if (lit) {
-                if (q.blocked) intensity = 0.0;
-                const double lcr = intensity * lt.colour[0], lcg = intensity * lt.colour[1], lcb = intensity * lt.colour[2];   // scaleColour (Image.fs:25-26)
-                // specularShader (Shading.fs:78-87)
-                double fr = 0.0, fg = 0.0, fb = 0.0;
-                {
-                    const V3 nn = normalise(sf.n);
-                    const double k2 = 2.0 * dot3(ld.x, ld.y, ld.z, nn.x, nn.y, nn.z);
-                    const V3 rl = normalise(V3{ld.x - k2 * nn.x, ld.y - k2 * nn.y, ld.z - k2 * nn.z});         // Vector.reflect (CommonTypes.fs:72)
-                    const V3 vd = normalise(V3{r.dx, r.dy, r.dz});
-                    const double si = pow(dot3(vd.x, vd.y, vd.z, -rl.x, -rl.y, -rl.z), mat.shineyness);
-                    if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
-                }
-                // reflectionShader is carried by the path weight (below); lambertianDiffuse (Shading.fs:65-70)
-                if (!ROUGH || mat.roughness == 0.0) {              // diffuseShader (Shading.fs:72-76)
-                    const double di = dot3(-ld.x, -ld.y, -ld.z, sf.n.x, sf.n.y, sf.n.z);
-                    fr = fr + di * (mat.colour[0] * lcr); fg = fg + di * (mat.colour[1] * lcg); fb = fb + di * (mat.colour[2] * lcb);
-                } else {                                           // roughDiffuse: Oren-Nayar (Shading.fs:50-63); the light colour is not used (sic)
-                    const double rough = mat.roughness * mat.roughness;
-                    const V3 nn = normalise(sf.n), nv = normalise(V3{-r.dx, -r.dy, -r.dz}), nl = normalise(V3{-ld.x, -ld.y, -ld.z});
-                    const double ray_angle = acos(dot3(nn.x, nn.y, nn.z, nv.x, nv.y, nv.z)), light_angle = acos(dot3(nn.x, nn.y, nn.z, nl.x, nl.y, nl.z));
-                    const double alpha = fs_max(ray_angle, light_angle), beta = fs_min(ray_angle, light_angle);
-                    const double A = 1.0 - 0.5 * rough / (rough + 0.33), B = 0.45 * rough / (rough + 0.09);
-                    const double kl = dot3(-ld.x, -ld.y, -ld.z, nn.x, nn.y, nn.z), kv = dot3(-r.dx, -r.dy, -r.dz, nn.x, nn.y, nn.z);
-                    const V3 tl = normalise(V3{-ld.x - kl * nn.x, -ld.y - kl * nn.y, -ld.z - kl * nn.z});   // perpendicularComponent (CommonTypes.fs:77-79)
-                    const V3 tr = normalise(V3{-r.dx - kv * nn.x, -r.dy - kv * nn.y, -r.dz - kv * nn.z});
-                    const double di = cos(light_angle) * (A + (B * fs_max(0.0, dot3(tl.x, tl.y, tl.z, tr.x, tr.y, tr.z)) * sin(alpha) * tan(beta)));
-                    fr = fr + di * mat.colour[0]; fg = fg + di * mat.colour[1]; fb = fb + di * mat.colour[2];
-                }
-                cr += fr; cg += fg; cb += fb;
+            if (l < 8) vis_lo |= occluded << (8 * l); else vis_hi |= occluded << (8 * (l - 8));
+        }
+        // ---------------- pass 2: the shaders (Shading.fs:50-107) with everything reloaded ------------------
+        Ray r{0, 0, 0, 0, 0, 0};
+        double w = 0.0; uint32_t slot = 0;
+        if (active) {
+            const uint32_t i = hit_list[j];
+            if (bounce == 0) { r = primary_ray(gen, i); w = 1.0; slot = i; }
+            else { r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i]; }
+        }
+        MaterialV mat = material_at(S, sf.material);               // per-lane gather (64 B records, L1/L2 resident)
+        if (FANCY) { if (active && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }   // Ray.textureDiffuse (Ray.fs:57-59)
+        double cr = 0.0, cg = 0.0, cb = 0.0;                       // sum over fragments (Seq.sumBy shader, Shading.fs:139)
+        for (int l = 0; l < n_lights; ++l) {
+            if (active && !lit) { cr += mat.colour[0]; cg += mat.colour[1]; cb += mat.colour[2]; }   // shadeIfRequired (Shading.fs:100-104)
+            if (!lit) continue;
+            cdp lp = S.lights + 12ull * (uint32_t)l;
+            const uint32_t kind = reinterpret_cast<cup>(lp + 10)[0];
+            const double occluded = (double)((l < 8 ? vis_lo >> (8 * l) : vis_hi >> (8 * (l - 8))) & 0xFFull);
+            double intensity; V3 ld;
+            if (kind == LT_POINT) {                                // Light.attenuate (Light.fs:16-17), lightDirection (Shading.fs:44-48)
+                const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
+                const double ddx = lp[0] - sox, ddy = lp[1] - soy, ddz = lp[2] - soz;
+                const double dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+                intensity = occluded != 0.0 ? 0.0 : 1.0 / (lp[3] + dist * (lp[4] + dist * lp[5]));
+                ld = normalise(V3{sf.p.x - lp[0], sf.p.y - lp[1], sf.p.z - lp[2]});
+            } else {
+                if (SOFT && kind == LT_SOFT) { const double samples = (double)reinterpret_cast<cip>(lp + 10)[1]; intensity = (samples - occluded) / samples; }
+                else intensity = occluded != 0.0 ? 0.0 : 1.0;
+                ld = {lp[0], lp[1], lp[2]};
             }
+            const double lcr = intensity * lp[6], lcg = intensity * lp[7], lcb = intensity * lp[8];   // scaleColour (Image.fs:25-26)
+            double fr = 0.0, fg = 0.0, fb = 0.0;
+            {                                                      // specularShader (Shading.fs:78-87)
+                const V3 nn = normalise(sf.n);
+                const double k2 = 2.0 * dot3(ld.x, ld.y, ld.z, nn.x, nn.y, nn.z);
+                const V3 rl = normalise(V3{ld.x - k2 * nn.x, ld.y - k2 * nn.y, ld.z - k2 * nn.z});         // Vector.reflect (CommonTypes.fs:72)
+                const V3 vd = normalise(V3{r.dx, r.dy, r.dz});
+                const double si = pow(dot3(vd.x, vd.y, vd.z, -rl.x, -rl.y, -rl.z), mat.shineyness);
+                if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
+            }
+            // reflectionShader is carried by the path weight (below)
+            if (!FANCY || mat.roughness == 0.0) {                  // diffuseShader -> lambertianDiffuse (Shading.fs:65-76)
+                const double di = dot3(-ld.x, -ld.y, -ld.z, sf.n.x, sf.n.y, sf.n.z);
+                fr = fr + di * (mat.colour[0] * lcr); fg = fg + di * (mat.colour[1] * lcg); fb = fb + di * (mat.colour[2] * lcb);
+            } else {                                               // roughDiffuse: Oren-Nayar (Shading.fs:50-63); the light colour is not used (sic)
+                const double rough = mat.roughness * mat.roughness;
+                const V3 nn = normalise(sf.n), nv = normalise(V3{-r.dx, -r.dy, -r.dz}), nl = normalise(V3{-ld.x, -ld.y, -ld.z});
+                const double ray_angle = acos(dot3(nn.x, nn.y, nn.z, nv.x, nv.y, nv.z)), light_angle = acos(dot3(nn.x, nn.y, nn.z, nl.x, nl.y, nl.z));
+                const double alpha = fs_max(ray_angle, light_angle), beta = fs_min(ray_angle, light_angle);
+                const double A = 1.0 - 0.5 * rough / (rough + 0.33), B = 0.45 * rough / (rough + 0.09);
+                const double kl = dot3(-ld.x, -ld.y, -ld.z, nn.x, nn.y, nn.z), kv = dot3(-r.dx, -r.dy, -r.dz, nn.x, nn.y, nn.z);
+                const V3 tl = normalise(V3{-ld.x - kl * nn.x, -ld.y - kl * nn.y, -ld.z - kl * nn.z});   // perpendicularComponent (CommonTypes.fs:77-79)
+                const V3 tr = normalise(V3{-r.dx - kv * nn.x, -r.dy - kv * nn.y, -r.dz - kv * nn.z});
+                const double di = cos(light_angle) * (A + (B * fs_max(0.0, dot3(tl.x, tl.y, tl.z, tr.x, tr.y, tr.z)) * sin(alpha) * tan(beta)));
+                fr = fr + di * mat.colour[0]; fg = fg + di * mat.colour[1]; fb = fb + di * mat.colour[2];
+            }
+            cr += fr; cg += fg; cb += fb;
         }
         if (active) {                                              // one ray per sample per bounce: no write conflicts, fixed order
             acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
         }
         // reflectionShader (Shading.fs:89-98): every one of the L fragments adds reflectance * colour(reflected ray);
-        // with deterministic lights those L sub-traces are identical, so one ray carries weight L * reflectance.
+        // those L sub-traces are identical (deterministic lights, or streams keyed without the parent light), so one
+        // ray carries weight L * reflectance.
         const bool spawn = lit && mat.reflectance > 0.0 && bounce < max_depth;
         const unsigned long long m = __ballot(spawn);
         const uint32_t cnt = (uint32_t)__popcll(m);
@@ -938,7 +968,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene Sg, Primary gen, RayB
     wave_add(&rc->rays_shadow, n_shadow_wave);
     wave_add(&rc->rays_reflect, n_refl_wave);
     wave_add(&rc->csg_overflow, n_ovf_wave);
-    // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts L shadow rays
+    // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts its shadow rays
     // and each reflective hit L reflection rays (Shading.fs:109-139).
     if (lane_id() == 0 && (n_hit_wave || n_refl_wave)) {
         const double mult = pow((double)n_lights, (double)bounce);
@@ -983,7 +1013,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene Sg, const dou
         Ray r{0, 0, 0, 0, 0, 0};
         if (q.active) r = {o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]};
         bool overflow;
-        trace<false>(S, r, q, lds, overflow);
+        trace<false, true>(S, r, q, lds, overflow);
         if (q.active) {
             const bool h = q.id0 != ID_MISS;
             hit[i] = h ? 1 : 0;
@@ -1011,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
         Ray r{0, 0, 0, 0, 0, 0};
         if (q.active) { r = {o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]}; q.max_dist = max_dist[i]; }
         bool overflow;
-        trace<true>(S, r, q, lds, overflow);
+        trace<true, true>(S, r, q, lds, overflow);
         if (q.active) { blocked[i] = q.blocked ? 1 : 0; if (overflow) atomicAdd(&rc->csg_overflow, 1ull); }
     }
 }
@@ -1019,7 +1049,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
 } // namespace
 
 typedef void (*ShadeKernel)(DevScene, Primary, RayBuf, HitBuf, const uint32_t*, RayBuf, double*, uint32_t, int, int, ChunkCounters*, RenderCounters*);
-static ShadeKernel shade_variant(int v) {
+static ShadeKernel shade_variant(int v) {                          // bit 0 FANCY, bit 1 SOFT, bit 2 MESH
     switch (v & 7) {
         case 0: return k_shade<false, false, false>;
         case 1: return k_shade<true, false, false>;
@@ -1036,7 +1066,8 @@ static ShadeKernel shade_variant(int v) {
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
 void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, ChunkCounters* cc, RenderCounters* rc) {
-    hipLaunchKernelGGL(k_closest, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, bounce, cc, rc);
+    if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, bounce, cc, rc);
+    else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, bounce, cc, rc);
 }
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
                   uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
@@ -1063,9 +1094,11 @@ void launch_debug_blocked(const Launch& L, const DevScene& S, const double* o, c
 // Resident workgroups per CU for the persistent grids (register- and LDS-limited).
 namespace ftk {
 static int clamp_blocks(int n) { return n < 1 ? 1 : (n > 8 ? 8 : n); }
-int occupancy_blocks_closest(size_t lds_bytes) {
+int occupancy_blocks_closest(size_t lds_bytes, int variant) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest, kBlock, lds_bytes) != hipSuccess) n = 2;
+    hipError_t e = (variant & 4) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<true>, kBlock, lds_bytes)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<false>, kBlock, lds_bytes);
+    if (e != hipSuccess) n = 2;
     return clamp_blocks(n);
 }
 int occupancy_blocks_shade(size_t lds_bytes, int variant) {

@@ -345,7 +345,11 @@ int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
     if (out.csg_capacity > 255) { err = "a CSG subtree can produce more than 255 hits per ray; lower csg_mesh_capacity"; return FT_ERR_UNSUPPORTED; }
     if (out.leaves.size() > ftd::ID_LEAF_MASK) { err = "too many primitive instances"; return FT_ERR_UNSUPPORTED; }
     if (out.textures.empty()) out.textures.push_back(ftd::Texture{});
-    for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) l.tan_half_scatter = std::tan(l.scatter / 2.0);
+    for (auto& l : out.lights) if (l.kind == ftd::LT_SOFT) {
+        l.tan_half_scatter = std::tan(l.scatter / 2.0);
+        if (l.samples > 255) { err = "softdirectional lights with more than 255 samples are not supported on the device path"; return FT_ERR_UNSUPPORTED; }
+    }
+    if (out.lights.size() > 16) { err = "more than 16 lights are not supported on the device path"; return FT_ERR_UNSUPPORTED; }
     if (out.tris.empty()) { out.tris.assign(9, 0.0); out.tri_orig.assign(1, 0u); }   // keep device pointers non-null
     if (out.culls.empty()) out.culls.push_back(ftd::CullRecord{});
     return FT_OK;
