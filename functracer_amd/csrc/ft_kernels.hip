@@ -674,6 +674,15 @@ FT_DEV uint32_t unit_batches_for(uint32_t n) {
     uint32_t u = n / (64u * waves * 4u);                            // aim at >= 4 units per wave
     return u < 1u ? 1u : (u > 16u ? 16u : u);
 }
+// Rays per batch.  A wave's cost grows with the number of DISTINCT scene items its rays touch, so when a launch has
+// fewer rays than the grid has lanes (late bounces: a few hundred incoherent reflection rays), the rays are spread
+// thinly — 32, 16, ... 1 per wave — over the otherwise idle waves instead of packing 64 unrelated rays into one.
+FT_DEV uint32_t batch_lanes_for(uint32_t n) {
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    uint32_t b = 64u;
+    while (b > 1u && n < b * waves) b >>= 1;
+    return b;
+}
 // The first unit of every wave is static (unit = global wave id: no atomic, so an empty or tiny launch costs no
 // traffic on the counter word at all); later units come from the cursor, which counts units beyond those.
 struct UnitCursor {
@@ -759,19 +768,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
     const uint32_t n = bounce == 0 ? gen.n_pix * (uint32_t)gen.spp : cc->n_rays[bounce];
-    const uint32_t unit = unit_batches_for(n);
+    const uint32_t unit = unit_batches_for(n), B = batch_lanes_for(n);
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
-    UnitCursor units(&cc->work_trace[bounce], unit * 64u);
+    UnitCursor units(&cc->work_trace[bounce], unit * B);
     for (;;) {
         const uint32_t ubase = units.next();
         if (ubase >= n) break;
         uint32_t mask_lo = 0, mask_hi = 0, unit_hits = 0;          // lane b keeps the hit mask of batch b of this unit
         for (uint32_t b = 0; b < unit; ++b) {
-            const uint32_t base = ubase + b * 64u;
+            const uint32_t base = ubase + b * B;
             if (base >= n) break;
             const uint32_t i = base + lane_id();
             Query<false> q;
-            q.active = i < n; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
+            q.active = i < n && lane_id() < B; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
             Ray r{0, 0, 0, 0, 0, 0};
             if (q.active) {
                 if (bounce == 0) r = primary_ray(gen, i);
@@ -795,7 +804,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
             for (uint32_t b = 0; b < unit; ++b) {
                 const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_lo, (int)b) |
                                              ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_hi, (int)b) << 32);
-                if ((m >> lane_id()) & 1ull) hit_list[dst + lanes_below(m)] = ubase + b * 64u + lane_id();
+                if ((m >> lane_id()) & 1ull) hit_list[dst + lanes_below(m)] = ubase + b * B + lane_id();
                 dst += (uint32_t)__popcll(m);
             }
         }
@@ -820,14 +829,14 @@ __global__ __launch_bounds__(kBlock, FANCY ? 1 : 3) void k_shade(DevScene Sg, Pr
     const uint32_t n = cc->n_hits[bounce];
     const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
-    const uint32_t unit = unit_batches_for(n);
-    UnitCursor units(&cc->work_shade[bounce], unit * 64u);
+    const uint32_t unit = unit_batches_for(n), B = batch_lanes_for(n);
+    UnitCursor units(&cc->work_shade[bounce], unit * B);
     for (uint32_t ub = 0, ubase = 0;; ++ub) {
         if (ub % unit == 0) ubase = units.next();
-        const uint32_t base = ubase + (ub % unit) * 64u;
+        const uint32_t base = ubase + (ub % unit) * B;
         if (base >= n) { if (ub % unit == 0) break; ub += unit - 1 - (ub % unit); continue; }
         const uint32_t j = base + lane_id();
-        const bool active = j < n;
+        const bool active = j < n && lane_id() < B;
         // ---------------- pass 1: surface point + visibility of every light -------------------------------
         Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
         bool lit = false;
