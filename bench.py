@@ -31,6 +31,23 @@ RAY_REC, HIT_REC = 60, 16         # bytes, functracer_amd/csrc/ft_device.h
 ALGO_BYTES_PER_RAY = 2 * RAY_REC + 2 * HIT_REC   # each record written once and read once
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """gloo announces its connections on stdout; rank 0's stdout must carry exactly one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,11 +74,19 @@ def main():
     import functracer_amd as ft
     from functracer_amd import tiling
 
+    n_visible = max(1, torch.cuda.device_count())
+    device = local_rank % n_visible               # more ranks than GPUs only happens in rehearsals on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")          # RCCL: used for the barrier / timing reduction only, never for pixels
-        host_group = dist.new_group(backend="gloo")
+        torch.cuda.set_device(device)
+        # The data path has no exchange step, so no RCCL collective exists to run over xGMI; the process group only
+        # carries the bench contract's barrier, three timing scalars and the host-side band gather: gloo on CPU tensors
+        # (FT_BENCH_BACKEND=nccl switches the barrier / scalars to RCCL).
+        backend = os.environ.get("FT_BENCH_BACKEND", "gloo")
+        with stdout_to_stderr():
+            dist.init_process_group(backend)
+            host_group = dist.group.WORLD if backend == "gloo" else dist.new_group(backend="gloo")
+            dist.barrier()
 
     def barrier_sync():
         if world > 1:
@@ -73,7 +98,7 @@ def main():
     base_spp = args.spp if args.spp else scene.samples
     spp = base_spp if args.strong else base_spp * world          # weak scaling: per-GPU samples stay those of the N = 1 run
     jitter = ft.jitter_pattern(spp)
-    ctx = ft.Context(device=local_rank)
+    ctx = ft.Context(device=device)
     scene.lower(ctx)
     bands = None if world == 1 else tiling.bands_for_rank(res_h, res_v, rank, world)
     frame = np.zeros((res_v, res_h, 3))
@@ -106,7 +131,9 @@ def main():
     vals = torch.tensor([wall, kernel_ms], dtype=torch.float64)
     tot = torch.tensor([float(rays)], dtype=torch.float64)
     if world > 1:
-        vals = vals.cuda(); tot = tot.cuda()
+        on_gpu = dist.get_backend() == "nccl"
+        if on_gpu:
+            vals = vals.cuda(); tot = tot.cuda()
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         vals = vals.cpu(); tot = tot.cpu()
