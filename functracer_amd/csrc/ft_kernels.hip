@@ -218,7 +218,7 @@ FT_DEV bool tri_hit(cdp T, const Ray& r, double& t_out) {
 }
 
 // BoundingBox.intersects (BoundingBox.fs:32-58), inverse direction precomputed per ray.
-FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz) {
+FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz, double* entry = nullptr) {
     struct { double bmin[3], bmax[3]; } n = {{nd[0], nd[1], nd[2]}, {nd[3], nd[4], nd[5]}};
     const bool nx = ivx < 0.0, ny = ivy < 0.0, nz = ivz < 0.0;
     double tmin = ((nx ? n.bmax[0] : n.bmin[0]) - r.ox) * ivx;
@@ -233,6 +233,7 @@ FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz) {
     if ((tmin > tzmax) || (tzmin > tmax)) return false;
     tmin = fs_max(tzmin, tmin);
     tmax = fs_min(tzmax, tmax);
+    if (entry) *entry = tmin;
     return (tmin < __builtin_inf()) && (tmax > -__builtin_inf());
 }
 
@@ -437,6 +438,74 @@ FT_DEV void mesh_bvh_query(const Scene& S, int32_t bvh_root, const Ray& r, Query
     if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
 }
 
+// Closest / any-hit over a reference-shaped BSP tree (BspMesh.fs:67-76).  Nodes are visited in the reference's
+// order (right subtree, then left; leaf triangles in list order), so "strictly smaller t wins" reproduces the
+// stable sort; a node is entered iff the reference's own box test passes AND the box can still hold a usable
+// hit (its entry distance is not beyond the current bound, with a margin far above the rounding of either side).
+// PACKET = the wave walks the tree together (uniform stack in the lanes of a VGPR, scalar loads).
+template <bool ANY, bool PACKET>
+FT_DEV void mesh_bsp_query(const Scene& S, int32_t root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit, int32_t* stack) {
+    bool alive = q.active && !(ANY && q.blocked);
+    if (!__any(alive)) return;
+    const double ivx = 1.0 / r.dx, ivy = 1.0 / r.dy, ivz = 1.0 / r.dz;
+    double bound = ANY ? q.max_dist : q.best_t;
+    uint32_t best_tri = 0u;
+    bool found = false;
+    int sp = 0, stack_lanes = 0;
+    int cur = PACKET ? root : (alive ? root : kDone);
+    for (;;) {
+        if (PACKET) {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            if (cur >= 0) {
+                cdp nd = S.nodes + 8ull * (uint32_t)cur;
+                double entry = 0.0;
+                const bool enter = alive && aabb_hit(nd, r, ivx, ivy, ivz, &entry) && !(entry > bound * (1.0 + 1e-12) + 1e-12);
+                if (__any(enter)) {
+                    cip ch = reinterpret_cast<cip>(nd + 6);
+                    const int left = ch[0];
+                    stack_lanes = ((int)lane_id() == sp) ? left : stack_lanes;
+                    ++sp; cur = ch[1];
+                    continue;
+                }
+            } else {
+                const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
+                for (uint32_t k = 0; k < count; ++k) {
+                    double t;
+                    if (alive && tri_hit(S.tris + 9ull * (first + k), r, t)) {
+                        if (ANY) { if (t < bound) { q.blocked = true; alive = false; } }
+                        else if (t < bound) { bound = t; best_tri = first + k; found = true; }
+                    }
+                }
+                if (ANY) { if (!__any(alive)) break; }
+            }
+            if (sp == 0) break;
+            --sp;
+            cur = __builtin_amdgcn_readlane(stack_lanes, sp);
+        } else {
+            if (!__any(cur != kDone)) break;
+            while (cur >= 0) {
+                cdp nd = S.nodes + 8ull * (uint32_t)cur;
+                double entry = 0.0;
+                if (aabb_hit(nd, r, ivx, ivy, ivz, &entry) && !(entry > bound * (1.0 + 1e-12) + 1e-12)) {
+                    cip ch = reinterpret_cast<cip>(nd + 6); stack[sp * kBlock] = ch[0]; ++sp; cur = ch[1];
+                } else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+                else cur = kDone;
+            }
+            if (cur != kDone) {
+                const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
+                for (uint32_t k = 0; k < count; ++k) {
+                    double t;
+                    if (!tri_hit(S.tris + 9ull * (first + k), r, t)) continue;
+                    if (ANY) { if (t < bound) { q.blocked = true; sp = 0; break; } }
+                    else if (t < bound) { bound = t; best_tri = first + k; found = true; }
+                }
+                if (sp > 0) { --sp; cur = stack[sp * kBlock]; } else cur = kDone;
+            }
+        }
+    }
+    if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
+}
+
 // The same query for a COHERENT wavefront (primary rays of one 8x8 pixel block and their shadow rays):
 // the 64 rays walk the BVH together.  The node stack and the current node are wave-uniform (the stack lives
 // in the lanes of one VGPR: lane i holds entry i, popped with v_readlane), node and triangle data come through scalar loads,
@@ -524,6 +593,14 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                         to_model(S.leaves + 16ull * arg, (H.flags & LF_XFORM) != 0, r, rm);
                         if (coherent) mesh_bvh_packet<ANY>(S, bvh, rm, q, arg, lit);
                         else mesh_bvh_query<ANY>(S, bvh, rm, q, arg, lit, stack);
+                        break;
+                    }
+                    const int32_t bsp_root = S.meshes[4 * H.mesh];
+                    if (bsp_root >= 0) {
+                        Ray rm;
+                        to_model(S.leaves + 16ull * arg, (H.flags & LF_XFORM) != 0, r, rm);
+                        if (coherent) mesh_bsp_query<ANY, true>(S, bsp_root, rm, q, arg, lit, stack);
+                        else mesh_bsp_query<ANY, false>(S, bsp_root, rm, q, arg, lit, stack);
                         break;
                     }
                 }

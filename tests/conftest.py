@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The libraries are built in-tree (and git-ignored): build them when a fresh checkout has none.
+    libs = [os.path.join(ROOT, "functracer_amd", "lib", "libfunctracer_hip.so"), os.path.join(ROOT, "functracer_amd", "lib", "libfunctracer_host.so"),
+            os.path.join(ROOT, "oracle", "libft_oracle.so")]
+    if not all(os.path.exists(p) for p in libs):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

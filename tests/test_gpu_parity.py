@@ -18,13 +18,6 @@ XFORMS = {
 }
 
 
-def both(build):
-    """Run the same builder program against a fresh oracle and the shared device context."""
-    orc = O.Oracle()
-    build(orc)
-    return orc
-
-
 def test_known_answers_through_the_device_path(hip, golden):
     for case in golden["hand_derived"]["closest"]:
         H.single_prim(hip, case["prim"], lights=False)
@@ -354,3 +347,27 @@ def test_multi_device_context_equals_single_device(hip):
     multi.render(p.camera, 320, 180, 2, jit, seed=3, tiles=[(16, 8, 64, 40)], out=part)
     assert np.array_equal(part[8:48, 16:80], want[8:48, 16:80]) and (part[:8] == -1.0).all()
     multi.close()
+
+
+def test_program_cli_writes_the_png(tmp_path):
+    """functracer_amd/host/Program.cpp (the C++ stand-in for Program.fs): scene file in, PNG out, on the GPU."""
+    import os
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(H.ROOT, "functracer_amd", "lib", "functracer")
+    out = tmp_path / "sample.png"
+    res = subprocess.run([exe, H.scene_path("sample-det"), str(out)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout == "" and "Shaded scene" in res.stderr          # nothing but the image may ever reach stdout
+    p = _load("sample-det")
+    orc = O.Oracle()
+    p.lower(orc)
+    w, h = p.resolution
+    want, _ = orc.render(p.camera, w, h, p.samples, ft.jitter_pattern(p.samples))
+    got = np.asarray(Image.open(out).convert("RGBA")).astype(int)
+    ref = O.quantise_rgba8(want).astype(int)
+    assert got.shape == ref.shape
+    # truncation to bytes is a step function of the pixel value: allow one level on the few channels that sit on a step
+    assert (np.abs(got - ref) <= 1).all() and (got != ref).mean() < 1e-3
+    res = subprocess.run([exe, str(tmp_path / "missing.scene")], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 1 and "cannot open" in res.stderr         # readScene: message + exit code 1 (Program.fs:10-16)
