@@ -1,4 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle.  Every test needs a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -371,3 +373,25 @@ def test_program_cli_writes_the_png(tmp_path):
     assert (np.abs(got - ref) <= 1).all() and (got != ref).mean() < 1e-3
     res = subprocess.run([exe, str(tmp_path / "missing.scene")], capture_output=True, text=True, timeout=60)
     assert res.returncode == 1 and "cannot open" in res.stderr         # readScene: message + exit code 1 (Program.fs:10-16)
+
+
+def test_config5_resolution_properties(hip):
+    """BASELINE config 5 geometry (3840x2160, tiled over 8 ranks) at 1 spp: band union == whole frame, and the
+    frame is linear in the light colours (every shader term is: Shading.fs:65-98) - exactly so for a factor 2."""
+    p = _load("bunny")
+    p.lower(hip)
+    w, h = 3840, 2160
+    jit = ft.jitter_pattern(1)
+    full, st = hip.render(p.camera, w, h, 1, jit)
+    assert st["rays_primary"] == w * h and np.isfinite(full).all() and full.max() > 0
+    from functracer_amd import tiling
+    tiled = np.zeros_like(full)
+    for r in range(8):
+        hip.render(p.camera, w, h, 1, jit, tiles=tiling.bands_for_rank(w, h, r, 8), out=tiled)
+    assert np.array_equal(tiled, full)
+    # same scene with the light twice as bright
+    scene2 = open(H.scene_path("bunny")).read().replace("colour (1,1,1)", "colour (2,2,2)")
+    p2 = ft.parse_scene(scene2, base_dir=os.path.join(H.ROOT, "scenes"))
+    p2.lower(hip)
+    bright, _ = hip.render(p2.camera, w, h, 1, jit)
+    assert np.array_equal(bright, 2.0 * full)
