@@ -898,7 +898,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
 // of the whole fragment state): pass 1 only decides visibility (one byte per light: occluded sample count),
 // pass 2 reloads the ray and the material and evaluates the shaders.
 template <bool FANCY, bool SOFT, bool MESH>
-__global__ __launch_bounds__(kBlock, FANCY ? 1 : 3) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
+__global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
                                                    double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
                                                    ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
