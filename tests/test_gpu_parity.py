@@ -281,7 +281,7 @@ def test_textures_and_oren_nayar(hip):
     assert worst < 1e-6
 
 
-STOCHASTIC = [("night-house", 160, 90, 3), ("sample-soft", 96, 96, 4), ("repeat", 160, 90, 2)]
+STOCHASTIC = [("night-house", 160, 90, 3), ("sample-soft", 96, 96, 4), ("repeat", 160, 90, 2), ("house", 160, 90, 2)]
 
 
 @pytest.mark.parametrize("name,w,h,spp", STOCHASTIC)
