@@ -43,7 +43,7 @@ struct ft_context {
     DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
-    DeviceBuf d_rays[2], d_hits, d_hit_list, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
+    DeviceBuf d_rays[2], d_hits, d_hit_list, d_touched, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
     int64_t ray_capacity = 0;
     std::vector<hipEvent_t> events;
     size_t events_used = 0;
@@ -105,6 +105,7 @@ int32_t ensure_frame_buffers(ft_context* c, int64_t cap) {
     for (int i = 0; i < 2; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_hits, (size_t)cap * 16)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_hit_list, (size_t)cap * 4)) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_touched, (size_t)cap)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_acc, (size_t)cap * 24)) != FT_OK) return rc;
     c->ray_capacity = cap;
     return FT_OK;
@@ -195,7 +196,7 @@ void ft_destroy(ft_context* c) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_out_index,
-                             &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
+                             &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
         for (auto e : c->events) (void)hipEventDestroy(e);
@@ -555,17 +556,15 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         timed(0, [&] { (void)hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream); });
         const ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
                                (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed};
-        timed(0, [&] { (void)hipMemsetAsync(c->d_acc.p, 0, (size_t)n_samples * 24, c->stream); });   // accumulators start at Colour.Zero
-        ++n_launches;
         for (int b = 0; b <= last_bounce; ++b) {
-            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), b, cc, rcount); });
+            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, cc, rcount); });
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
             n_launches += 2;
         }
         const uint32_t* out_index = !whole ? nullptr : (corner ? c->d_out_index.as<uint32_t>() : c->d_pixels.as<uint32_t>()) + job.out_base;
         double* out_ptr = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
-        if (corner) timed(3, [&] { ftk::launch_blend_corner(Lg, c->d_acc.as<double>(), n_samples, job.w, job.h, out_index, out_ptr); });
-        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), n_samples, n_pix, spp, out_index, out_ptr); });
+        if (corner) timed(3, [&] { ftk::launch_blend_corner(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, job.w, job.h, out_index, out_ptr); });
+        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, spp, out_index, out_ptr); });
         ++n_launches;
     }
     ev1 = boundary;

@@ -74,17 +74,19 @@ struct Primary {
     uint32_t stride;               // ids are y*stride + x: res_h for pixels, res_h + 1 for the corner grid of `samples corner`
     unsigned long long seed;       // keys the counter-based streams of soft shadows / depth of field
 };
-// K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.
-void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce,
+// K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.  Bounce 0 also records, one
+// byte per sample, whether the primary ray hit anything (`touched`): untouched samples are Colour.Zero and their accumulator is
+// neither cleared nor read.
+void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce,
                     ChunkCounters* cc, RenderCounters* rc);
 // K3: shading + shadow rays + accumulation for the compacted hits of bounce k; emits bounce k+1 rays.
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
                   double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
 // out_index == nullptr: pixel p is written at out_rgb + 3p (packed); else at out_rgb + 3*out_index[p] (in place in the frame).
-void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb);
+void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb);
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
-void launch_blend_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
+void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,
                           int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc);

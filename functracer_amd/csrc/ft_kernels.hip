@@ -840,7 +840,7 @@ FT_DEV Ray primary_ray(const Primary& g, uint32_t i) {
 }
 
 template <bool MESH>
-__global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, int bounce,
+__global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, uint8_t* __restrict__ touched, int bounce,
                                                      ChunkCounters* cc, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
@@ -868,6 +868,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
             trace<false, MESH>(S, r, q, lds, overflow, bounce == 0);   // primary rays of one pixel block walk meshes as a packet
             const bool hit = q.active && q.id0 != ID_MISS;
             if (q.active) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }
+            if (bounce == 0 && q.active) touched[i] = hit ? 1 : 0;  // samples whose primary ray misses stay Colour.Zero: never stored, never read
             const unsigned long long m = __ballot(hit);
             if (lane_id() == b) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); }
             unit_hits += (uint32_t)__popcll(m);
@@ -1029,7 +1030,11 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
             cr += fr; cg += fg; cb += fb;
         }
         if (active) {                                              // one ray per sample per bounce: no write conflicts, fixed order
-            acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
+            if (bounce == 0) {                                     // first contribution of the sample: 0 + x = x, so a plain store replaces clear + add
+                acc[slot] = w * cr; acc[(size_t)acc_stride + slot] = w * cg; acc[2 * (size_t)acc_stride + slot] = w * cb;
+            } else {
+                acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
+            }
         }
         // reflectionShader (Shading.fs:89-98): every one of the L fragments adds reflectance * colour(reflected ray);
         // those L sub-traces are identical (deterministic lights, or streams keyed without the parent light), so one
@@ -1062,11 +1067,13 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* __restrict__ out_index, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, const uint8_t* __restrict__ touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp,
+                                                   const uint32_t* __restrict__ out_index, double* __restrict__ out) {
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
         double r = 0.0, g = 0.0, b = 0.0;                          // Array.average: sum from Zero in sample order, then DivideByInt
         for (int s = 0; s < spp; ++s) {
             const size_t i = (size_t)s * n_pix + p;
+            if (!touched[i]) continue;                             // a sample that hit nothing is Colour.Zero: x + 0 = x
             r += acc[i]; g += acc[(size_t)acc_stride + i]; b += acc[2 * (size_t)acc_stride + i];
         }
         const size_t o = out_index ? out_index[p] : p;
@@ -1074,14 +1081,14 @@ __global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_blend_corner(const double* __restrict__ acc, uint32_t acc_stride, uint32_t w, uint32_t h,
+__global__ __launch_bounds__(kBlock) void k_blend_corner(const double* __restrict__ acc, const uint8_t* __restrict__ touched, uint32_t acc_stride, uint32_t w, uint32_t h,
                                                           const uint32_t* __restrict__ out_index, double* __restrict__ out) {
     const uint32_t n = w * h, cs = w + 1;
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
         const uint32_t y = p / w, x = p - y * w;
         const uint32_t c[4] = {y * cs + x, y * cs + x + 1, (y + 1) * cs + x, (y + 1) * cs + x + 1};   // Image.fs:139
         double r = 0.0, g = 0.0, b = 0.0;                          // Seq.average: sum in corner order, / 4
-        for (int k = 0; k < 4; ++k) { r += acc[c[k]]; g += acc[(size_t)acc_stride + c[k]]; b += acc[2 * (size_t)acc_stride + c[k]]; }
+        for (int k = 0; k < 4; ++k) { if (!touched[c[k]]) continue; r += acc[c[k]]; g += acc[(size_t)acc_stride + c[k]]; b += acc[2 * (size_t)acc_stride + c[k]]; }
         const size_t o = out_index ? out_index[p] : p;
         out[3 * o] = r / 4.0; out[3 * o + 1] = g / 4.0; out[3 * o + 2] = b / 4.0;
     }
@@ -1151,20 +1158,20 @@ static ShadeKernel shade_variant(int v) {                          // bit 0 FANC
 // ============================================================================================ launchers
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
-void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, ChunkCounters* cc, RenderCounters* rc) {
-    if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, bounce, cc, rc);
-    else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, bounce, cc, rc);
+void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, ChunkCounters* cc, RenderCounters* rc) {
+    if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, touched, bounce, cc, rc);
+    else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, touched, bounce, cc, rc);
 }
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
                   uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
     auto k = shade_variant(L.variant);
     hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
 }
-void launch_blend(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
-    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, n_pix, spp, out_index, out_rgb);
+void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
+    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, spp, out_index, out_rgb);
 }
-void launch_blend_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb) {
-    hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, w, h, out_index, out_rgb);
+void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb) {
+    hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, w, h, out_index, out_rgb);
 }
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n, int32_t* hit, double* t,
                           double* p, double* nrm, double* colour, RenderCounters* rc) {
