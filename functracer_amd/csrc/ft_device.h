@@ -11,6 +11,7 @@ namespace ftk {
 
 constexpr int kBlock = 256;        // 4 wavefronts of 64; waves never synchronise with each other
 constexpr int kMaxBounce = 16;     // recursion limits above this are rejected by ft_render
+constexpr int kWorkGroups = 64;    // independent work cursors per launch
 
 struct DevScene {
     const double* leaves;          // n_leaves x 16 doubles (ftd::Leaf)
@@ -39,8 +40,9 @@ constexpr uint64_t kRayRecBytes = 60, kHitRecBytes = 16;
 struct ChunkCounters {
     uint32_t n_rays[kMaxBounce + 2];   // rays queued for bounce k
     uint32_t n_hits[kMaxBounce + 2];   // compacted lit/unlit hit count of bounce k
-    uint32_t work_trace[kMaxBounce + 2]; // work-stealing cursors
-    uint32_t work_shade[kMaxBounce + 2];
+    // Work cursors: kWorkGroups independent counters per kernel and bounce, one 64-byte line each (see ft_kernels.hip).
+    uint32_t work_trace[kMaxBounce + 2][kWorkGroups * 16];
+    uint32_t work_shade[kMaxBounce + 2][kWorkGroups * 16];
 };
 // Per-render device statistics (zeroed before every render).
 struct RenderCounters {

@@ -742,16 +742,29 @@ FT_DEV void textured_colour(const Scene& S, const MaterialV& mat, double u, doub
     for (uint32_t h = 0; h < mat.hue_rot; ++h) { const double r = col[0], g = col[1], b = col[2]; col[0] = b; col[1] = r; col[2] = g; }   // CommonTypes.fs:90
 }
 
-// Work distribution.  A persistent wave pulls a UNIT of up to 16 consecutive 64-ray batches with one
-// returning atomic: a single device-scope counter word saturates at about 88 dequeues per microsecond on
-// this chip (MI355X_MICROARCH.md, row "dequeue"), which with one atomic per 64 rays capped every kernel at
-// ~5.6 Grays/s.  The unit shrinks with the launch size so that small launches still spread over all waves.
-FT_DEV uint32_t unit_batches_for(uint32_t n) {
-    const uint32_t waves = gridDim.x * (kBlock / 64);
-    uint32_t u = n / (64u * waves * 4u);                            // aim at >= 4 units per wave
-    return u < 1u ? 1u : (u > 16u ? 16u : u);
-}
-// Rays per batch.  A wave's cost grows with the number of DISTINCT scene items its rays touch, so when a launch has
+// Work distribution.  The batches of a launch (batch b = rays b*B .. b*B+B-1) are split into kWorkGroups interleaved
+// classes (b mod 64); wave w pulls batches of class w mod 64 from that class's own cursor, one returning atomic per
+// batch, issued one batch ahead so its latency hides behind the current batch.  Why 64 cursors and not one: a single
+// device-scope word serves about 88 dequeues per microsecond (MI355X_MICROARCH.md row "dequeue"); with one shared
+// cursor that capped every kernel at 5.6 Grays/s (one atomic per batch) and still cost 0.2 ms per 8.4 M-ray launch
+// of an EMPTY scene with one atomic per 16 batches (all waves queue on the word together).  Purely static striding
+// removes the atomics but loses 20-50 % on scenes whose batches differ widely in cost.  64 lines, about 80 waves
+// each, keep every word far below its service rate and keep the balancing dynamic.
+struct BatchCursor {
+    uint32_t* ctr; uint32_t cls;
+    FT_DEV BatchCursor(uint32_t* counters) {
+        const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+        cls = wave % (uint32_t)kWorkGroups;
+        ctr = counters + 16u * cls;
+    }
+    FT_DEV uint32_t grab() {                                        // index of the next batch of this wave's class
+        uint32_t k = 0;
+        if (lane_id() == 0) k = atomicAdd(ctr, 1u);
+        return cls + (uint32_t)kWorkGroups * (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    }
+};
+//
+// Rays per batch: a wave's cost grows with the number of DISTINCT scene items its rays touch, so when a launch has
 // fewer rays than the grid has lanes (late bounces: a few hundred incoherent reflection rays), the rays are spread
 // thinly — 32, 16, ... 1 per wave — over the otherwise idle waves instead of packing 64 unrelated rays into one.
 FT_DEV uint32_t batch_lanes_for(uint32_t n) {
@@ -760,19 +773,6 @@ FT_DEV uint32_t batch_lanes_for(uint32_t n) {
     while (b > 1u && n < b * waves) b >>= 1;
     return b;
 }
-// The first unit of every wave is static (unit = global wave id: no atomic, so an empty or tiny launch costs no
-// traffic on the counter word at all); later units come from the cursor, which counts units beyond those.
-struct UnitCursor {
-    uint32_t* cursor; uint32_t rays_per_unit; bool first;
-    FT_DEV UnitCursor(uint32_t* c, uint32_t rays) : cursor(c), rays_per_unit(rays), first(true) {}
-    FT_DEV uint32_t next() {
-        const uint32_t waves = gridDim.x * (kBlock / 64);
-        if (first) { first = false; return (blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * rays_per_unit; }
-        uint32_t u = 0;
-        if (lane_id() == 0) u = atomicAdd(cursor, 1u);
-        return (__builtin_amdgcn_readfirstlane(u) + waves) * rays_per_unit;
-    }
-};
 
 FT_DEV void wave_add(unsigned long long* dst, unsigned long long v_per_lane_flag_count) {
     // caller passes an already wave-reduced value from lane 0 only
@@ -821,12 +821,20 @@ FT_DEV unsigned long long sample_id(const Primary& g, uint32_t slot) {
 // Primary rays are never stored: bounce 0 of k_closest / k_shade regenerates them from the sample index
 // (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
 // 64 pixels of one 8x8 block for one jitter offset).
-FT_DEV Ray primary_ray(const Primary& g, uint32_t i) {
+FT_DEV uint32_t primary_pixel(const Primary& g, uint32_t i) {        // the one memory access a primary ray needs
     const uint32_t s = i / g.n_pix, pl = i - s * g.n_pix;
-    const uint32_t pid = g.pixel_ids[g.pix_base + pl];
+    return g.pixel_ids[g.pix_base + pl];
+}
+// `uniform_s`: all 64 lanes of the batch share one jitter offset (n_pix is a multiple of 64): it is then read
+// through a scalar load, which does not queue behind the wave's outstanding vector stores.
+FT_DEV Ray primary_ray_from(const Primary& g, uint32_t i, uint32_t pid, bool uniform_s) {
+    const uint32_t s = i / g.n_pix;
     const uint32_t py = pid / g.stride, px = pid - py * g.stride;
     const double centre_x = g.cam.tlx + (double)px * g.cam.pw, centre_y = g.cam.tly - (double)py * g.cam.ph;
-    const double jx = centre_x + g.jitter[2 * s] * g.cam.pw, jy = centre_y + g.jitter[2 * s + 1] * g.cam.ph;
+    double ox, oy;
+    if (uniform_s) { cdp J = to_const_as(g.jitter) + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)s); ox = J[0]; oy = J[1]; }
+    else { ox = g.jitter[2 * s]; oy = g.jitter[2 * s + 1]; }
+    const double jx = centre_x + ox * g.cam.pw, jy = centre_y + oy * g.cam.ph;
     Ray r{g.cam.o[0], g.cam.o[1], g.cam.o[2],
           (g.cam.k[0] + jx * g.cam.i[0]) + jy * g.cam.j[0], (g.cam.k[1] + jx * g.cam.i[1]) + jy * g.cam.j[1], (g.cam.k[2] + jx * g.cam.i[2]) + jy * g.cam.j[2]};
     if (g.cam.has_focus) {                                         // ImagePlane.depthOfFieldJitter (Image.fs:91-94, Ray.fs:15-18)
@@ -838,6 +846,7 @@ FT_DEV Ray primary_ray(const Primary& g, uint32_t i) {
     }
     return r;
 }
+FT_DEV Ray primary_ray(const Primary& g, uint32_t i) { return primary_ray_from(g, i, primary_pixel(g, i), false); }
 
 template <bool MESH>
 __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, uint8_t* __restrict__ touched, int bounce,
@@ -845,49 +854,63 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
     const uint32_t n = bounce == 0 ? gen.n_pix * (uint32_t)gen.spp : cc->n_rays[bounce];
-    const uint32_t unit = unit_batches_for(n), B = batch_lanes_for(n);
+    const uint32_t B = batch_lanes_for(n);
+    const uint32_t n_batches = (n + B - 1) / B;
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
-    UnitCursor units(&cc->work_trace[bounce], unit * B);
-    for (;;) {
-        const uint32_t ubase = units.next();
-        if (ubase >= n) break;
-        uint32_t mask_lo = 0, mask_hi = 0, unit_hits = 0;          // lane b keeps the hit mask of batch b of this unit
-        for (uint32_t b = 0; b < unit; ++b) {
-            const uint32_t base = ubase + b * B;
-            if (base >= n) break;
-            const uint32_t i = base + lane_id();
-            Query<false> q;
-            q.active = i < n && lane_id() < B; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
-            Ray r{0, 0, 0, 0, 0, 0};
-            if (q.active) {
-                if (bounce == 0) r = primary_ray(gen, i);
-                else r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
-                r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
-            }
-            bool overflow;
-            trace<false, MESH>(S, r, q, lds, overflow, bounce == 0);   // primary rays of one pixel block walk meshes as a packet
-            const bool hit = q.active && q.id0 != ID_MISS;
-            if (q.active) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }
-            if (bounce == 0 && q.active) touched[i] = hit ? 1 : 0;  // samples whose primary ray misses stay Colour.Zero: never stored, never read
-            const unsigned long long m = __ballot(hit);
-            if (lane_id() == b) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); }
-            unit_hits += (uint32_t)__popcll(m);
-            n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
-        }
-        // wave-ballot / prefix-sum compaction of the rays that hit: one reservation per unit
-        uint32_t dst = 0;
-        if (lane_id() == 0 && unit_hits) dst = atomicAdd(&cc->n_hits[bounce], unit_hits);
-        dst = __builtin_amdgcn_readfirstlane(dst);
-        if (unit_hits) {
-            for (uint32_t b = 0; b < unit; ++b) {
-                const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_lo, (int)b) |
-                                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_hi, (int)b) << 32);
-                if ((m >> lane_id()) & 1ull) hit_list[dst + lanes_below(m)] = ubase + b * B + lane_id();
+    // Compaction of the rays that hit (wave ballot + prefix sum): hit masks of up to 16 batches are parked in the
+    // lanes of three VGPRs (lane k = k-th pending batch) and flushed with ONE reservation on the hit counter.
+    uint32_t mask_lo = 0, mask_hi = 0, base_of = 0, pending = 0, pending_hits = 0;
+    auto flush = [&]() {
+        if (pending_hits) {
+            uint32_t dst = 0;
+            if (lane_id() == 0) dst = atomicAdd(&cc->n_hits[bounce], pending_hits);
+            dst = __builtin_amdgcn_readfirstlane(dst);
+            for (uint32_t k = 0; k < pending; ++k) {
+                const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_lo, (int)k) |
+                                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_hi, (int)k) << 32);
+                const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)base_of, (int)k);
+                if ((m >> lane_id()) & 1ull) hit_list[dst + lanes_below(m)] = bs + lane_id();
                 dst += (uint32_t)__popcll(m);
             }
         }
-        n_hit_wave += unit_hits;
+        n_hit_wave += pending_hits;
+        pending = 0; pending_hits = 0;
+    };
+    // Vector memory operations of a wave complete in issue order, so a load issued after the previous batch's stores
+    // would wait for those stores to be acknowledged: the pixel id of the wave's NEXT batch is requested before the
+    // current one is traced and stored.
+    const bool uniform_s = bounce == 0 && B == 64u && (gen.n_pix & 63u) == 0u;
+    BatchCursor cursor(&cc->work_trace[bounce][0]);
+    uint32_t bi = cursor.grab(), bi_next = cursor.grab();           // two deep: the index after next is in flight while this batch runs
+    uint32_t pid_next = 0;
+    if (bounce == 0 && bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(gen, bi * B + lane_id());
+    for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
+        const uint32_t base = bi * B;
+        const uint32_t i = base + lane_id();
+        const uint32_t pid = pid_next;
+        if (bounce == 0 && bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(gen, bi_next * B + lane_id());
+        Query<false> q;
+        q.active = i < n && lane_id() < B; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
+        Ray r{0, 0, 0, 0, 0, 0};
+        if (q.active) {
+            if (bounce == 0) r = primary_ray_from(gen, i, pid, uniform_s);
+            else r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
+            r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
+        }
+        bool overflow;
+        trace<false, MESH>(S, r, q, lds, overflow, bounce == 0);   // primary rays of one pixel block walk meshes as a packet
+        const bool hit = q.active && q.id0 != ID_MISS;
+        if (hit) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }   // only rays that hit are ever looked at again
+        if (bounce == 0 && q.active) touched[i] = hit ? 1 : 0;      // samples whose primary ray misses stay Colour.Zero: never stored, never read
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            if (lane_id() == pending) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); base_of = base; }
+            ++pending; pending_hits += (uint32_t)__popcll(m);
+            if (pending == 16u) flush();
+        }
+        n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
     }
+    flush();
     if (bounce == 0) wave_add(&rc->hits_primary, n_hit_wave);
     wave_add(&rc->csg_overflow, n_ovf_wave);
 }
@@ -907,12 +930,11 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
     const uint32_t n = cc->n_hits[bounce];
     const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
-    const uint32_t unit = unit_batches_for(n), B = batch_lanes_for(n);
-    UnitCursor units(&cc->work_shade[bounce], unit * B);
-    for (uint32_t ub = 0, ubase = 0;; ++ub) {
-        if (ub % unit == 0) ubase = units.next();
-        const uint32_t base = ubase + (ub % unit) * B;
-        if (base >= n) { if (ub % unit == 0) break; ub += unit - 1 - (ub % unit); continue; }
+    const uint32_t B = batch_lanes_for(n);
+    const uint32_t n_batches = (n + B - 1) / B;
+    BatchCursor cursor(&cc->work_shade[bounce][0]);
+    for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
+        const uint32_t base = bi * B;
         const uint32_t j = base + lane_id();
         const bool active = j < n && lane_id() < B;
         // ---------------- pass 1: surface point + visibility of every light -------------------------------

@@ -420,11 +420,12 @@ struct BspBuilder {
 
     // ---- device-side BVH over the triangles of a top-level Leaf (see ft_flat.h) -----------------
     struct Box { double lo[3], hi[3]; };
+    static constexpr size_t kBvhLeafTris = 4;
     uint32_t bvh_depth = 0;
     int32_t bvh_build(const std::vector<Tri3>& ts, const std::vector<Box>& boxes, std::vector<uint32_t>& idx, size_t lo, size_t hi,
                       uint32_t first_global, double pad, uint32_t level) {
         if (level + 1 > bvh_depth) bvh_depth = level + 1;
-        if (hi - lo <= 2) {                                                     // leaf: a reordered copy of the triangles + their list indices
+        if (hi - lo <= kBvhLeafTris) {                                          // leaf: a reordered copy of the triangles + their list indices
             ftd::BspLeaf L{(uint32_t)(out.tris.size() / 9), (uint32_t)(hi - lo)};
             for (size_t k = lo; k < hi; ++k) {
                 const Tri3& t = ts[idx[k]];
