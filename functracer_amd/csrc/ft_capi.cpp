@@ -336,7 +336,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_culls, f.culls)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters))) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 1))) != FT_OK) return rc;
     FT_HIP(c, hipStreamSynchronize(c->stream));
     ftk::DevScene& S = c->dev_scene;
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
@@ -516,7 +516,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
     else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
     if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
-    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 1), c->stream));
 
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
@@ -567,6 +567,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, spp, out_index, out_ptr); });
         ++n_launches;
     }
+    timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, ftk::kStatSlots); });
     ev1 = boundary;
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipStreamSynchronize(c->stream));

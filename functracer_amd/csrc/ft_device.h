@@ -89,6 +89,9 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
 void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb);
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
 void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
+// Sum the per-wave statistic slots 1..n_slots into slot 0 (one block).
+constexpr uint32_t kStatSlots = 8192;   // >= waves of the largest persistent grid (256 CUs x 8 blocks x 4 waves)
+void launch_reduce_stats(const Launch& L, RenderCounters* slots, uint32_t n_slots);
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,
                           int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc);

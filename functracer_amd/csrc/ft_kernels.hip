@@ -774,10 +774,11 @@ FT_DEV uint32_t batch_lanes_for(uint32_t n) {
     return b;
 }
 
-FT_DEV void wave_add(unsigned long long* dst, unsigned long long v_per_lane_flag_count) {
-    // caller passes an already wave-reduced value from lane 0 only
-    if (lane_id() == 0 && v_per_lane_flag_count) atomicAdd(dst, v_per_lane_flag_count);
-}
+// Per-render statistics: every wave of the persistent grid owns one RenderCounters slot (plain read-modify-write,
+// launches on a stream are serialised) and k_reduce_stats sums the slots once per render.  Atomics on shared words
+// at the end of every launch (thousands of waves finishing together) cost about 10 % of the bunny frame.
+FT_DEV RenderCounters* my_stats(RenderCounters* slots) { return slots + 1 + (blockIdx.x * (kBlock / 64) + threadIdx.x / 64); }   // slot 0 = the total
+FT_DEV void wave_add(unsigned long long* dst, unsigned long long v) { if (lane_id() == 0 && v) *dst += v; }
 
 // ---------------------------------------------------------------------------------------------
 // Seeded counter-based stream standing in for the reference's unseeded System.Random (Jitter.fs:27, Image.fs:101):
@@ -911,8 +912,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
         n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
     }
     flush();
-    if (bounce == 0) wave_add(&rc->hits_primary, n_hit_wave);
-    wave_add(&rc->csg_overflow, n_ovf_wave);
+    RenderCounters* mine = my_stats(rc);
+    if (bounce == 0) wave_add(&mine->hits_primary, n_hit_wave);
+    wave_add(&mine->csg_overflow, n_ovf_wave);
 }
 
 // k_shade variants: FANCY = Oren-Nayar and grid textures compiled in (libm-heavy code: acos, tan, atan2 ...),
@@ -1078,14 +1080,34 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
         n_refl_wave += cnt;
         n_hit_wave += (unsigned long long)__popcll(__ballot(active));
     }
-    wave_add(&rc->rays_shadow, n_shadow_wave);
-    wave_add(&rc->rays_reflect, n_refl_wave);
-    wave_add(&rc->csg_overflow, n_ovf_wave);
+    RenderCounters* mine = my_stats(rc);
+    wave_add(&mine->rays_shadow, n_shadow_wave);
+    wave_add(&mine->rays_reflect, n_refl_wave);
+    wave_add(&mine->csg_overflow, n_ovf_wave);
     // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts its shadow rays
     // and each reflective hit L reflection rays (Shading.fs:109-139).
     if (lane_id() == 0 && (n_hit_wave || n_refl_wave)) {
         const double mult = pow((double)n_lights, (double)bounce);
-        atomicAdd(&rc->ref_equiv, mult * ((double)Sg.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave));
+        mine->ref_equiv += mult * ((double)Sg.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, uint32_t n_slots) {   // one block; slot 0 receives the totals
+    __shared__ RenderCounters part[kBlock];
+    RenderCounters s{0, 0, 0, 0, 0.0, 0.0};
+    for (uint32_t k = 1 + threadIdx.x; k <= n_slots; k += kBlock) {
+        s.rays_shadow += slots[k].rays_shadow; s.rays_reflect += slots[k].rays_reflect; s.hits_primary += slots[k].hits_primary;
+        s.csg_overflow += slots[k].csg_overflow; s.ref_equiv += slots[k].ref_equiv;
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        RenderCounters t = slots[0];                              // debug kernels add to slot 0 directly
+        for (int k = 0; k < kBlock; ++k) {
+            t.rays_shadow += part[k].rays_shadow; t.rays_reflect += part[k].rays_reflect; t.hits_primary += part[k].hits_primary;
+            t.csg_overflow += part[k].csg_overflow; t.ref_equiv += part[k].ref_equiv;
+        }
+        slots[0] = t;
     }
 }
 
@@ -1194,6 +1216,9 @@ void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, ui
 }
 void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, w, h, out_index, out_rgb);
+}
+void launch_reduce_stats(const Launch& L, RenderCounters* slots, uint32_t n_slots) {
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(kBlock), 0, L.stream, slots, n_slots);
 }
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n, int32_t* hit, double* t,
                           double* p, double* nrm, double* colour, RenderCounters* rc) {
