@@ -618,8 +618,13 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                 cdp C = S.culls + 24ull * arg;
                 const double ocx = r.ox - C[0], ocy = r.oy - C[1], ocz = r.oz - C[2];
                 const double dd = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz), b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz), cc = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
-                // squared distance from the centre to the ray's LINE exceeds the inflated radius (negative t matters under CSG)
+                // (1) the squared distance from the centre to the ray's LINE exceeds the inflated radius: no hit at any t;
+                // (2) the origin is outside the sphere and moving away: every hit of the item has t < 0, which neither
+                //     closest (Scene.fs:115) nor lightIsBocked (Scene.fs:121) ever uses (CSG state inside the item is moot).
+                // (A distance test against the light / the closest hit so far was measured: its two square roots per item cost
+                //  more than the extra skips return.)
                 bool miss = (cc * dd - b * b) > (C[3] * dd + 1e-12 * (cc * dd)) && dd > 0.0;
+                if (cc > C[3] && b > 0.0) miss = true;
                 const int n_rows = (int)C[4];
                 for (int k = 0; k < n_rows; ++k)                   // near-parallel to a plane-derived face: Plane.fs:13-16 may hit at the origin
                     if (fabs(dot3(C[5 + 3 * k], C[6 + 3 * k], C[7 + 3 * k], r.dx, r.dy, r.dz)) < 2.0 * kEps) miss = false;
@@ -858,7 +863,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
     const uint32_t B = batch_lanes_for(n);
     const uint32_t n_batches = (n + B - 1) / B;
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
-    // Compaction of the rays that hit (wave ballot + prefix sum): hit masks of up to 16 batches are parked in the
+    // Compaction of the rays that hit (wave ballot + prefix sum): hit masks of up to 48 batches are parked in the
     // lanes of three VGPRs (lane k = k-th pending batch) and flushed with ONE reservation on the hit counter.
     uint32_t mask_lo = 0, mask_hi = 0, base_of = 0, pending = 0, pending_hits = 0;
     auto flush = [&]() {
@@ -907,7 +912,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
         if (m) {
             if (lane_id() == pending) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); base_of = base; }
             ++pending; pending_hits += (uint32_t)__popcll(m);
-            if (pending == 16u) flush();
+            if (pending == 48u) flush();
         }
         n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
     }
