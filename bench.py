@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 RAY_REC, HIT_REC = 60, 16         # bytes, functracer_amd/csrc/ft_device.h
-ALGO_BYTES_PER_RAY = 2 * RAY_REC + 2 * HIT_REC   # each record written once and read once
+SURVEY_BYTES_PER_RAY = 2 * RAY_REC + 2 * HIT_REC   # SURVEY 8(d)'s stored-wavefront model restated with this build's sizeof
 
 
 import contextlib
@@ -155,13 +155,14 @@ def main():
         mrays_kernel = rays_total / (kernel_ms_max * 1e-3) / 1e6       # same rays over the HIP-event kernel time of the slowest rank
         dom = max(("closest", "shade"), key=lambda k: k_times[k])
         dom_avg_ms = k_times[dom] / max(1, k_launch[dom])
-        # rays a launch of the dominant kernel processes: closest sees every ray; shade sees the hits (its shadow rays are its work)
+        # Algorithmic bytes of the dominant kernel = what its launches have to move by construction of the pipeline (ft_stats,
+        # DESIGN.md): primary rays are regenerated (4 B pixel id + 1 B flag), only hits and reflection rays have records in HBM.
         rays_rank = rays / steps
-        if dom == "closest":
-            rays_per_launch = (st["rays_primary"] + st["rays_reflect"]) / max(1, k_launch[dom] / steps)
-        else:
-            rays_per_launch = st["rays_shadow"] / max(1, k_launch[dom] / steps)
-        achieved = ALGO_BYTES_PER_RAY * rays_per_launch / (dom_avg_ms * 1e-3) / 1e9
+        launches_per_step = max(1, k_launch[dom] / steps)
+        algo_bytes_per_launch = st["algorithmic_bytes_" + dom] / launches_per_step
+        achieved = algo_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
+        rays_per_launch = (st["rays_primary"] + st["rays_reflect"] if dom == "closest" else st["rays_shadow"]) / launches_per_step
+        survey_model = SURVEY_BYTES_PER_RAY * rays_per_launch / (dom_avg_ms * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (primary+shadow+reflect) at 1920x1080x16spp; frame ms",
             "value": round(mrays_wall, 3),
@@ -184,7 +185,10 @@ def main():
             "gather_ms": round(gather_ms, 3),
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
-                         "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_ray": ALGO_BYTES_PER_RAY},
+                         "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": round(algo_bytes_per_launch),
+                         "rays_per_launch": round(rays_per_launch),
+                         "survey_stored_wavefront_model": {"bytes_per_ray": SURVEY_BYTES_PER_RAY, "GBps": round(survey_model, 1),
+                                                           "note": "what a design that stores every ray and hit record would move; this build regenerates primary rays"}},
             "per_kernel_ms_per_step": {k: round(v / steps, 4) for k, v in k_times.items()},
         }
         traffic_file = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.scene}.json")

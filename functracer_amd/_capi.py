@@ -55,7 +55,8 @@ class ft_stats(C.Structure):
                 ("rays_traced", C.c_uint64), ("rays_reference_equivalent", C.c_double), ("hits_primary", C.c_uint64),
                 ("csg_overflow", C.c_uint64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double),
                 ("trace_kernel_ms", C.c_double), ("algorithmic_bytes", C.c_uint64), ("n_launches", C.c_int32),
-                ("n_chunks", C.c_int32)]
+                ("n_chunks", C.c_int32), ("hits_total", C.c_uint64), ("algorithmic_bytes_closest", C.c_uint64),
+                ("algorithmic_bytes_shade", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

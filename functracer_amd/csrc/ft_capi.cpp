@@ -422,7 +422,8 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
             stats->rays_primary += s.rays_primary; stats->rays_shadow += s.rays_shadow; stats->rays_reflect += s.rays_reflect; stats->rays_traced += s.rays_traced;
             stats->rays_reference_equivalent += s.rays_reference_equivalent; stats->hits_primary += s.hits_primary; stats->csg_overflow += s.csg_overflow;
             stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms); stats->trace_kernel_ms = std::max(stats->trace_kernel_ms, s.trace_kernel_ms);
-            stats->algorithmic_bytes += s.algorithmic_bytes; stats->n_launches += s.n_launches; stats->n_chunks += s.n_chunks;
+            stats->algorithmic_bytes += s.algorithmic_bytes; stats->hits_total += s.hits_total; stats->algorithmic_bytes_closest += s.algorithmic_bytes_closest;
+            stats->algorithmic_bytes_shade += s.algorithmic_bytes_shade; stats->n_launches += s.n_launches; stats->n_chunks += s.n_chunks;
         }
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
@@ -587,7 +588,15 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         stats->rays_reference_equivalent = (double)stats->rays_primary + hrc.ref_equiv;
         stats->hits_primary = hrc.hits_primary; stats->csg_overflow = hrc.csg_overflow;
         stats->kernel_ms = ms; stats->trace_kernel_ms = c->k_ms[1] + c->k_ms[2];
-        stats->algorithmic_bytes = (2 * ftk::kRayRecBytes + 2 * ftk::kHitRecBytes) * stats->rays_traced + 24ull * (uint64_t)n_pix_total;
+        {   // bytes the pipeline has to move by construction (ft_device.h); P primary rays, R reflection rays, H hits, H0 primary hits
+            const uint64_t P = stats->rays_primary, R = hrc.rays_reflect, H = hrc.hits_total, H0 = hrc.hits_primary, HL = H - std::min(H, H0);
+            stats->hits_total = H;
+            stats->algorithmic_bytes_closest = P * (ftk::kPixelIdBytes + ftk::kTouchedBytes) + R * 48 + H * (ftk::kHitRecBytes + ftk::kListBytes);
+            stats->algorithmic_bytes_shade = H * (ftk::kHitRecBytes + ftk::kListBytes) + H0 * (2 * ftk::kPixelIdBytes + ftk::kAccBytes) +
+                                             HL * (48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + R * ftk::kRayRecBytes;
+            stats->algorithmic_bytes = stats->algorithmic_bytes_closest + stats->algorithmic_bytes_shade +
+                                       P * ftk::kTouchedBytes + H0 * ftk::kAccBytes + 24ull * (uint64_t)n_pix_total;   // + k_blend
+        }
         stats->n_launches = n_launches; stats->n_chunks = n_chunks;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }

@@ -35,6 +35,11 @@ struct DevScene {
 struct RayBuf { double *ox, *oy, *oz, *dx, *dy, *dz, *w; uint32_t* slot; };
 struct HitBuf { double* t; uint32_t* id0; uint32_t* id1; };
 constexpr uint64_t kRayRecBytes = 60, kHitRecBytes = 16;
+// Bytes a launch has to move per unit, by construction of the pipeline (roofline): a primary ray costs a 4-byte
+// pixel id read and a 1-byte flag write (it is regenerated, never stored); a reflection ray a 60-byte record written once and
+// read in k_closest (48 B: origin + direction) and twice in k_shade; a hit a 16-byte record + 4-byte list entry, written once,
+// read once; an accumulator 24 B stored (bounce 0) or read-modify-written (later bounces); a pixel 24 B out.
+constexpr uint64_t kPixelIdBytes = 4, kTouchedBytes = 1, kListBytes = 4, kAccBytes = 24;
 
 // Per-chunk device counters (zeroed before every chunk).
 struct ChunkCounters {
@@ -48,7 +53,7 @@ struct ChunkCounters {
 struct RenderCounters {
     unsigned long long rays_shadow, rays_reflect, hits_primary, csg_overflow;
     double ref_equiv;
-    double pad;
+    unsigned long long hits_total;      // hits shaded over all bounces
 };
 
 struct Camera {                    // ImagePlane (Image.fs:55-63), computed on the host

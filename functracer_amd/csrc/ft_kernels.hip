@@ -1088,6 +1088,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
     RenderCounters* mine = my_stats(rc);
     wave_add(&mine->rays_shadow, n_shadow_wave);
     wave_add(&mine->rays_reflect, n_refl_wave);
+    wave_add(&mine->hits_total, n_hit_wave);
     wave_add(&mine->csg_overflow, n_ovf_wave);
     // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts its shadow rays
     // and each reflective hit L reflection rays (Shading.fs:109-139).
@@ -1099,10 +1100,10 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
 
 __global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, uint32_t n_slots) {   // one block; slot 0 receives the totals
     __shared__ RenderCounters part[kBlock];
-    RenderCounters s{0, 0, 0, 0, 0.0, 0.0};
+    RenderCounters s{0, 0, 0, 0, 0.0, 0};
     for (uint32_t k = 1 + threadIdx.x; k <= n_slots; k += kBlock) {
         s.rays_shadow += slots[k].rays_shadow; s.rays_reflect += slots[k].rays_reflect; s.hits_primary += slots[k].hits_primary;
-        s.csg_overflow += slots[k].csg_overflow; s.ref_equiv += slots[k].ref_equiv;
+        s.csg_overflow += slots[k].csg_overflow; s.ref_equiv += slots[k].ref_equiv; s.hits_total += slots[k].hits_total;
     }
     part[threadIdx.x] = s;
     __syncthreads();
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, 
         RenderCounters t = slots[0];                              // debug kernels add to slot 0 directly
         for (int k = 0; k < kBlock; ++k) {
             t.rays_shadow += part[k].rays_shadow; t.rays_reflect += part[k].rays_reflect; t.hits_primary += part[k].hits_primary;
-            t.csg_overflow += part[k].csg_overflow; t.ref_equiv += part[k].ref_equiv;
+            t.csg_overflow += part[k].csg_overflow; t.ref_equiv += part[k].ref_equiv; t.hits_total += part[k].hits_total;
         }
         slots[0] = t;
     }

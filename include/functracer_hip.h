@@ -116,9 +116,12 @@ typedef struct ft_stats {
     double   kernel_ms;      /* HIP-event time over all kernels of the call, on the library's stream */
     double   wall_ms;        /* host wall time of the call incl. copies                        */
     double   trace_kernel_ms;/* HIP-event time of the closest-hit + shade/shadow kernels only  */
-    uint64_t algorithmic_bytes; /* sizeof(RayRec)*2+sizeof(HitRec)*2 per traced ray + 24 B/pixel */
+    uint64_t algorithmic_bytes; /* bytes the pipeline has to move for this frame by construction (roofline) */
     int32_t  n_launches;
     int32_t  n_chunks;
+    uint64_t hits_total;     /* hits shaded over all bounces                                   */
+    uint64_t algorithmic_bytes_closest; /* the k_closest share of algorithmic_bytes            */
+    uint64_t algorithmic_bytes_shade;   /* the k_shade share                                   */
 } ft_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */

@@ -2,8 +2,10 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE), collected as
 MI355X_MICROARCH.md §HBM prescribes: separate --pmc passes, values in KiB, and on gfx950 FETCH_SIZE
 under-reports coalesced streaming reads (exactly 1/2 for 16 B/lane).  This path reads 8 B/lane, an
-uncalibrated width, so the read side is calibrated in the same pass on a kernel whose bytes are known:
-k_blend reads exactly 24*spp B and writes 24 B per pixel.
+uncalibrated width; it was calibrated while k_blend still read every accumulator (exactly 24*spp B per pixel):
+factor 1.979 and 1.9998 in two separate passes (profiles/r01_d_*, r01_j_pmc_traffic_bunny.json), WRITE_SIZE
+exact (1.0004).  The read side is therefore doubled (--read-scale 2.0); k_blend's write (24 B per pixel) is
+still checked in every run as `write_ratio`.
 
   python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --pixels 2073600 --spp 16
 """
@@ -34,17 +36,15 @@ def main():
     ap.add_argument("write_dir")
     ap.add_argument("--pixels", type=int, required=True)
     ap.add_argument("--spp", type=int, required=True)
-    ap.add_argument("--chunks", type=int, default=0, help="launches of k_blend per frame (default: counted)")
+    ap.add_argument("--read-scale", type=float, default=2.0, help="FETCH_SIZE correction for this path's coalesced 8 B/lane reads")
     args = ap.parse_args()
     fetch, write = load(args.fetch_dir, "FETCH_SIZE"), load(args.write_dir, "WRITE_SIZE")
     n_blend = len(fetch.get("k_blend", [])) or 1
-    known_read = 24.0 * args.spp * args.pixels / n_blend          # per k_blend launch
-    known_write = 24.0 * args.pixels / n_blend
-    blend_read = sum(fetch["k_blend"]) / n_blend
+    known_write = 24.0 * args.pixels / n_blend                     # per k_blend launch
     blend_write = sum(write["k_blend"]) / max(1, len(write["k_blend"]))
-    read_scale = known_read / blend_read                           # correction for 8 B/lane coalesced reads
-    out = {"calibration": {"kernel": "k_blend", "known_read_bytes_per_launch": known_read, "FETCH_SIZE_bytes_per_launch": blend_read,
-                           "read_scale": read_scale, "known_write_bytes_per_launch": known_write, "WRITE_SIZE_bytes_per_launch": blend_write,
+    read_scale = args.read_scale
+    out = {"calibration": {"read_scale": read_scale, "read_scale_source": "k_blend full-accumulator passes r01_d / r01_j: 1.979, 1.9998",
+                           "known_write_bytes_per_launch_k_blend": known_write, "WRITE_SIZE_bytes_per_launch_k_blend": blend_write,
                            "write_ratio": blend_write / known_write}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
