@@ -5,9 +5,9 @@
 //   k_closest   closest hit         Scene.fs:112-118 over the flattened Scene.intersect (Scene.fs:67-104)
 //   k_shade     Phong + shadow rays + reflection spawn   Shading.fs:24-139
 //   k_blend     per-pixel mean      Image.fs:112-116
-// k_closest / k_shade run once per bounce on wavefront ray buffers in HBM; rays that terminate
-// are dropped by wave-ballot / prefix-sum compaction, so every lane of the next stage is live.
-// All kernels use persistent grids whose waves pull 64-ray batches from an atomic cursor.
+// k_closest / k_shade run once per bounce; reflection rays and hit records live in wavefront buffers in
+// HBM, rays that terminate are dropped by wave-ballot / prefix-sum compaction, so every lane of the next stage
+// is live.  Both are persistent grids whose waves pull 64-ray batches from 64 interleaved cursors.
 //
 // Execution model notes (wave64, CDNA4):
 //   * one lane = one ray; the scene program, leaf records, matrices, materials, lights and
@@ -15,7 +15,8 @@
 //   * FP64 throughout (the reference is F# float); no MFMA — this is branchy scalar geometry;
 //   * per-lane CSG hit lists and BSP node stacks live in LDS, laid out [entry][lane] so that a
 //     wave access is always bank-conflict free whatever entry each lane touches;
-//   * waves are independent: no __syncthreads anywhere.
+//   * waves are independent: no __syncthreads in any tracing kernel;
+//   * coherent wavefronts (one 8x8 pixel block) walk mesh trees as a packet with a wave-uniform stack.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -1160,7 +1161,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene Sg, const dou
         if (q.active) {
             const bool h = q.id0 != ID_MISS;
             hit[i] = h ? 1 : 0;
-            Surface sf{{0, 0, 0}, {1, 0, 0}, 0};
+            Surface sf{{0, 0, 0}, {1, 0, 0}, 0, 0.0, 0.0};
             double col[3] = {1, 1, 1};
             if (h) { sf = surface_at<true>(S, r, q.best_t, q.id0, q.id1); MaterialV m = material_at(S, sf.material); if (m.texture >= 0) textured_colour(S, m, sf.u, sf.v, m.colour); col[0] = m.colour[0]; col[1] = m.colour[1]; col[2] = m.colour[2]; }
             t[i] = h ? q.best_t : 0.0;

@@ -489,8 +489,8 @@ struct BspBuilder {
         const double inf = std::numeric_limits<double>::infinity();            // BoundingBox.pointsBoundry, BoundingBox.fs:9-22
         P3 lo{inf, inf, inf}, hi{-inf, -inf, -inf};
         auto grow = [&](P3 q) {
-            if (q.x < lo.x) lo.x = q.x; if (q.y < lo.y) lo.y = q.y; if (q.z < lo.z) lo.z = q.z;
-            if (q.x > hi.x) hi.x = q.x; if (q.y > hi.y) hi.y = q.y; if (q.z > hi.z) hi.z = q.z;
+            lo.x = std::min(lo.x, q.x); lo.y = std::min(lo.y, q.y); lo.z = std::min(lo.z, q.z);
+            hi.x = std::max(hi.x, q.x); hi.y = std::max(hi.y, q.y); hi.z = std::max(hi.z, q.z);
         };
         for (auto& t : ts) { grow(t.a); grow(t.b); grow(t.c); }
         const double wx = std::fabs(hi.x - lo.x) / 2.0, wy = std::fabs(hi.y - lo.y) / 2.0, wz = std::fabs(hi.z - lo.z) / 2.0;  // optimalSplit, BspMesh.fs:30-41

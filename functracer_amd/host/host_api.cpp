@@ -171,7 +171,7 @@ int32_t fth_scene_lower(const fth_scene* s, const fth_builder* b, void* ctx) {
     if (!s || !b) return FT_ERR_INVALID;
     int32_t rc = b->scene_clear(ctx);
     if (rc != FT_OK) return rc;
-    Lowerer L{b, ctx};
+    Lowerer L{b, ctx, FT_OK, {}};
     ft_node root = L.lower(s->scene.objects);
     if (L.status != FT_OK) return L.status;
     for (const Light& l : s->scene.lights) {
