@@ -211,6 +211,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!c || !key) return FT_ERR_INVALID;
     if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; for (ft_context* p : c->peers) p->chunk_samples = value; return FT_OK; }
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
+    if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
     return FT_ERR_INVALID;
 }

@@ -261,7 +261,7 @@ struct Flattener {
                 break;
             }
             case GraphNode::Mesh: {
-                uint32_t mesh = mesh_for(id, n.tris.data(), (int64_t)(n.tris.size() / 9), n.depth);
+                uint32_t mesh = mesh_for(id, n.tris.data(), (int64_t)(n.tris.size() / 9), g.mesh_unclipped_bvh ? 0 : n.depth);
                 ItemMark im = begin_item(in_csg);
                 if (status == FT_OK) {
                     if (in_csg) out.mesh_under_csg = true;

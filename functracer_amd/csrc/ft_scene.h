@@ -53,6 +53,10 @@ struct SceneGraph {
     int32_t root = -1;
     std::vector<ftd::Light> lights;
     int32_t csg_mesh_capacity = 32;
+    // Non-default fast mode: ignore the `depth` of bspMesh and trace every mesh through the device-side BVH over
+    // its ORIGINAL triangles.  The reference clips triangles at BSP planes; unclipped triangles give the same surface but the
+    // hit arithmetic differs in the last bits, so pixels may differ at the 1e-12 level (and on silhouette ties).
+    bool mesh_unclipped_bvh = false;
 
     bool valid(int32_t id) const { return id >= 0 && id < (int32_t)nodes.size(); }
     // Returns FT_OK or a negative ft_status with err set.

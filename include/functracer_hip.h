@@ -132,7 +132,9 @@ int32_t ft_abi_version(void);
 int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out);
 void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);
-/* Tunables: "chunk_samples" (samples in flight per launch), "csg_mesh_capacity". */
+/* Tunables: "chunk_samples" (samples in flight per launch), "csg_mesh_capacity" (hit-list entries a mesh may add under
+ * CSG), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
+ * differ from the reference-shaped clipped BSP in the last bits).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
 
 /* ---- scene graph builder (Scene.fs:8-53) ------------------------------------------------- */
