@@ -68,6 +68,8 @@ def host_lib():
         lib.fth_parse_ply.argtypes = [C.c_char_p, _capi.c_double_p, C.c_int64, C.c_char_p, C.c_int32]
         lib.fth_jitter_pattern.argtypes = [C.c_uint64, C.c_int32, _capi.c_double_p]
         lib.fth_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]
+        lib.fth_load_image.restype = C.c_int64
+        lib.fth_load_image.argtypes = [C.c_char_p, _capi.c_int32_p, _capi.c_int32_p, C.POINTER(C.c_uint8), C.c_int64, C.c_char_p, C.c_int32]
         _host = lib
     return _host
 
@@ -156,6 +158,19 @@ def write_png(path, rgba):
     rc = host_lib().fth_write_png(os.fspath(path).encode(), rgba.ctypes.data_as(C.POINTER(C.c_uint8)), w, h)
     if rc < 0:
         raise FtError(rc, "write_png")
+
+
+def load_image(path):
+    """Image.Load<Rgb24> for local PNG / PPM files (Textures/Image.fs:21-26): (height, width, 3) uint8, row 0 = top."""
+    lib = host_lib()
+    w, h = C.c_int32(), C.c_int32()
+    err = C.create_string_buffer(512)
+    n = lib.fth_load_image(os.fspath(path).encode(), C.byref(w), C.byref(h), None, 0, err, 512)
+    if n < 0:
+        raise FtError(int(n), err.value.decode())
+    out = np.empty(n, dtype=np.uint8)
+    lib.fth_load_image(os.fspath(path).encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_uint8)), n, err, 512)
+    return out.reshape(h.value, w.value, 3)
 
 
 class Context(SceneBuilder):

@@ -77,6 +77,7 @@ BUILDER_SIGNATURES = [
     ("sg_group", C.c_int32, [C.c_void_p, c_int32_p, C.c_int32]),
     ("sg_csg", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     ("sg_texture_grid", C.c_int32, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int32, C.c_int32]),
+    ("sg_texture_image", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_int32]),
     ("scene_clear", C.c_int32, [C.c_void_p]),
     ("scene_set_objects", C.c_int32, [C.c_void_p, C.c_int32]),
     ("scene_add_directional", C.c_int32, [C.c_void_p, c_double_p, c_double_p]),
@@ -214,6 +215,14 @@ class SceneBuilder:
     def texture_grid(self, colour_a, colour_b, uv_ops, child):
         ops = as_f64(uv_ops).reshape(-1, 3) if len(uv_ops) else np.zeros((0, 3))
         return self._check(self._f("sg_texture_grid")(self._ctx, vec3(colour_a), vec3(colour_b), dptr(ops), ops.shape[0], child))
+
+    def texture_image(self, pixels, uv_ops, child):
+        """pixels: (height, width, 3) uint8, row 0 = top (image.SavePixelData() of an Rgb24 image)."""
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        assert px.ndim == 3 and px.shape[2] == 3
+        ops = as_f64(uv_ops).reshape(-1, 3) if len(uv_ops) else np.zeros((0, 3))
+        return self._check(self._f("sg_texture_image")(self._ctx, px.ctypes.data_as(C.POINTER(C.c_uint8)), px.shape[1], px.shape[0],
+                                                       dptr(ops), ops.shape[0], child))
 
     # Scene.Scene / Light --------------------------------------------------------------
     def clear(self):

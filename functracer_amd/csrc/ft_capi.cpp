@@ -40,7 +40,7 @@ struct ft_context {
     int64_t chunk_samples = 8ll << 20;
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_touched, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
@@ -195,7 +195,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_out_index,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_out_index,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -265,7 +265,15 @@ ft_node ft_sg_texture_grid(ft_context* c, const double ca[3], const double cb[3]
     fth::GraphNode n; n.kind = fth::GraphNode::Texture;
     std::memcpy(n.ca, ca, sizeof n.ca); std::memcpy(n.cb, cb, sizeof n.cb);
     n.uv_ops.assign(uv_ops, uv_ops + 3 * n_uv_ops); n.children = {child};
-    return add_node(c, std::move(n));                               // rejected at commit until textures reach the device path
+    return add_node(c, std::move(n));
+}
+
+ft_node ft_sg_texture_image(ft_context* c, const uint8_t* rgb24, int32_t width, int32_t height, const double* uv_ops, int32_t n_uv_ops, ft_node child) {
+    if (!c || !c->graph.valid(child) || !rgb24 || width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 28) || n_uv_ops < 0 || (n_uv_ops > 0 && !uv_ops)) return FT_ERR_INVALID;
+    fth::GraphNode n; n.kind = fth::GraphNode::Texture;
+    n.pixels.assign(rgb24, rgb24 + (size_t)width * height * 3); n.img_w = width; n.img_h = height;
+    n.uv_ops.assign(uv_ops, uv_ops + 3 * n_uv_ops); n.children = {child};
+    return add_node(c, std::move(n));
 }
 
 int32_t ft_scene_clear(ft_context* c) {
@@ -329,6 +337,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_materials, f.materials)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_lights, f.lights)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_textures, f.textures)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_tex_pixels, f.tex_pixels)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_program, f.program)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_meshes, f.meshes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_nodes, f.nodes)) != FT_OK) return rc;
@@ -343,7 +352,7 @@ static int32_t upload_scene(ft_context* c) {
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
     S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>(); S.textures = c->d_textures.as<ftd::Texture>();
     S.program = c->d_program.as<uint32_t>(); S.meshes = c->d_meshes.as<ftd::Mesh>();
-    S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>(); S.tri_orig = c->d_tri_orig.as<uint32_t>();
+    S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>(); S.tri_orig = c->d_tri_orig.as<uint32_t>(); S.tex_pixels = c->d_tex_pixels.as<uint8_t>();
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
     S.shadow_rays_per_hit = 0;

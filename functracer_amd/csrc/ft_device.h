@@ -26,6 +26,7 @@ struct DevScene {
     const double* tris;            // 9 per triangle: v0, e1, e2
     const double* culls;           // 24 doubles per ftd::CullRecord
     const uint32_t* tri_orig;      // 1 per triangle
+    const uint8_t* tex_pixels;     // Rgb24 rows of the image textures (ftd::Texture::pixel_base indexes into it)
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
     int32_t shadow_rays_per_hit, pad;   // sum over lights of the shadow rays the reference casts per hit
 };

@@ -57,11 +57,12 @@ struct Material {          // Ray.fs:4-10; 64 bytes
 // Scene.Texture (Scene.fs:47-53): a Grid under at most 5 uv functions, outermost (applied first) first.
 // 24 doubles.  op kind 0 = Texture.scale (u/a, v/b) (Texture.fs:14-16); kind 1 = Texture.rotate with
 // a = cos, b = sin of the angle (Texture.fs:18-22).
-struct Texture {
-    double c1[3], c2[3];
+struct Texture {             // Scene.Texture (Scene.fs:47-53) flattened; 192 bytes = 24 doubles
+    double c1[3], c2[3];     // Grid: the two colours.  Image: c1[0] = width, c1[1] = height
     double n_ops;
-    double ops[5][3];
-    double pad[2];
+    double ops[5][3];        // uv functions outermost first: {0, sx, sy} scale | {1, cos a, sin a} rotate
+    double kind;             // 0 = Texture.grid, 1 = ImageTexture.image
+    double pixel_base;       // Image: byte offset of its Rgb24 rows in DevScene::tex_pixels
 };
 
 enum LightKind : uint32_t { LT_DIRECTIONAL = 0, LT_SOFT = 1, LT_POINT = 2 };

@@ -60,6 +60,7 @@ struct Scene {
     cdp tris;         // 9 doubles per triangle
     cdp culls;        // 24 doubles per ftd::CullRecord
     cup tri_orig;     // 1 per triangle
+    const uint8_t* tex_pixels;   // per-lane byte gathers: ordinary global loads
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
 };
 static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
@@ -71,6 +72,7 @@ FT_DEV Scene scene_view(const DevScene& g) {
     s.program = to_const_as(g.program); s.meshes = to_const_as(reinterpret_cast<const int32_t*>(g.meshes));
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig);
+    s.tex_pixels = g.tex_pixels;
     s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
     return s;
 }
@@ -742,9 +744,21 @@ FT_DEV void textured_colour(const Scene& S, const MaterialV& mat, double u, doub
         else { const double x = a * u + 0.0 * 0.0 + b * v, z = -b * u + 0.0 * 0.0 + a * v; u = x; v = z; }
     }
     const double ru = fabs(u - floor(u)), rv = fabs(v - floor(v));                 // Texture.repeat
-    const bool first = (ru < 0.5 && rv < 0.5) ? true : (ru < 0.5) ? false : (ru > 0.5 && rv > 0.5);
-    cdp c = first ? T : T + 3;
-    col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
+    if (T[22] != 0.0) {                                                            // ImageTexture.image (Textures/Image.fs:27-35): nearest texel
+        const double w = T[0], h = T[1];
+        const double x = floor(ru * w), y = floor(rv * h);
+        // index = y*(3*width) + 3*x as the reference computes it (x == width wraps into the next row).  Past the last
+        // byte the reference raises IndexOutOfRange; this path reads the last texel instead (and texel 0 for NaN).
+        double idx = y * (3.0 * w) + 3.0 * x;
+        const double last = 3.0 * (w * h - 1.0);
+        idx = idx >= 0.0 ? (idx <= last ? idx : last) : 0.0;
+        const uint8_t* px = S.tex_pixels + (uint64_t)T[23] + (uint64_t)idx;
+        col[0] = (double)px[0] / 255.0; col[1] = (double)px[1] / 255.0; col[2] = (double)px[2] / 255.0;
+    } else {
+        const bool first = (ru < 0.5 && rv < 0.5) ? true : (ru < 0.5) ? false : (ru > 0.5 && rv > 0.5);
+        cdp c = first ? T : T + 3;
+        col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
+    }
     for (uint32_t h = 0; h < mat.hue_rot; ++h) { const double r = col[0], g = col[1], b = col[2]; col[0] = b; col[1] = r; col[2] = g; }   // CommonTypes.fs:90
 }
 

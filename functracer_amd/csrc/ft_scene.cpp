@@ -99,6 +99,7 @@ struct Flattener {
     int32_t status = FT_OK;
     int csg_depth = 0, max_csg_depth = 0;
     int cur_list = 0, max_list = 0;                  // static bound on the per-lane hit-list length
+    std::map<const GraphNode*, size_t> image_base;   // image texture node -> offset of its pixels in out.tex_pixels
 
     Flattener(const SceneGraph& g_, FlatScene& o, std::string& e) : g(g_), out(o), err(e) {}
 
@@ -123,8 +124,18 @@ struct Flattener {
             } else if (f.kind == GraphNode::Texture) {
                 ftd::Texture t{};
                 for (int a = 0; a < 3; ++a) { t.c1[a] = f.node->ca[a]; t.c2[a] = f.node->cb[a]; }
+                if (!f.node->pixels.empty()) {                               // ImageTexture.image (Textures/Image.fs:20-36)
+                    auto it = image_base.find(f.node);
+                    if (it == image_base.end()) {
+                        it = image_base.emplace(f.node, out.tex_pixels.size()).first;
+                        out.tex_pixels.insert(out.tex_pixels.end(), f.node->pixels.begin(), f.node->pixels.end());
+                    }
+                    t.kind = 1.0; t.pixel_base = (double)it->second;
+                    t.c1[0] = (double)f.node->img_w; t.c1[1] = (double)f.node->img_h; t.c1[2] = 0.0;
+                    t.c2[0] = t.c2[1] = t.c2[2] = 0.0;
+                }
                 size_t n_ops = f.node->uv_ops.size() / 3;
-                if (n_ops > 5) { status = FT_ERR_UNSUPPORTED; err = "more than 5 nested texture functions on one grid texture"; n_ops = 5; }   // flatten fails; keep the record well-formed
+                if (n_ops > 5) { status = FT_ERR_UNSUPPORTED; err = "more than 5 nested texture functions on one texture"; n_ops = 5; }   // flatten fails; keep the record well-formed
                 t.n_ops = (double)n_ops;
                 for (size_t k = 0; k < n_ops; ++k) {
                     const double kind = f.node->uv_ops[3 * k], a = f.node->uv_ops[3 * k + 1], b = f.node->uv_ops[3 * k + 2];

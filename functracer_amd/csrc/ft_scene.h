@@ -23,6 +23,8 @@ struct GraphNode {
     std::vector<int32_t> children;
     double ca[3] = {0}, cb[3] = {0};  // Texture grid colours
     std::vector<double> uv_ops;
+    std::vector<uint8_t> pixels;      // Texture image: Rgb24 rows (empty = grid)
+    int32_t img_w = 0, img_h = 0;
 };
 
 struct FlatScene {
@@ -31,6 +33,7 @@ struct FlatScene {
     std::vector<ftd::Material> materials;
     std::vector<ftd::Light> lights;
     std::vector<ftd::Texture> textures;
+    std::vector<uint8_t> tex_pixels;  // Rgb24 rows of all image textures, back to back
     std::vector<uint32_t> program;
     std::vector<ftd::Mesh> meshes;
     std::vector<ftd::BspNode> nodes;

@@ -24,6 +24,7 @@ static const fth_builder kHipBuilder = {
     [](void* c, const ft_node* ch, int32_t n) { return ft_sg_group((ft_context*)c, ch, n); },
     [](void* c, int32_t op, ft_node a, ft_node b) { return ft_sg_csg((ft_context*)c, op, a, b); },
     [](void* c, const double* ca, const double* cb, const double* ops, int32_t n, ft_node ch) { return ft_sg_texture_grid((ft_context*)c, ca, cb, ops, n, ch); },
+    [](void* c, const uint8_t* px, int32_t w, int32_t h, const double* ops, int32_t n, ft_node ch) { return ft_sg_texture_image((ft_context*)c, px, w, h, ops, n, ch); },
     [](void* c) { return ft_scene_clear((ft_context*)c); },
     [](void* c, ft_node r) { return ft_scene_set_objects((ft_context*)c, r); },
     [](void* c, const double* d, const double* col) { return ft_scene_add_directional((ft_context*)c, d, col); },

@@ -7,6 +7,7 @@
 #ifndef FUNCTRACER_HOST_SCENE_HPP
 #define FUNCTRACER_HOST_SCENE_HPP
 #include <array>
+#include <cstdint>
 #include <memory>
 #include <string>
 #include <vector>
@@ -43,7 +44,9 @@ struct TextureFunction { enum Kind { Scale, Rotate } kind; double a = 1, b = 1; 
 struct Texture {                                                   // Scene.fs:47-50
     enum Kind { Grid, Image } kind = Grid;
     Colour c1, c2;
-    std::string source;                                            // Image: path / URL (not loadable here)
+    std::string source;                                            // Image: path as written in the scene
+    std::shared_ptr<const std::vector<uint8_t>> pixels;            // Image: Rgb24 rows, top first (image.SavePixelData(), Textures/Image.fs:23)
+    int width = 0, height = 0;
     std::vector<TextureFunction> functions;                        // outermost first
 };
 
@@ -103,6 +106,8 @@ struct Scene {                                                     // Scene.fs:1
 bool parseScene(const std::string& text, const std::string& baseDir, SceneOptions& options, Scene& scene, std::string& error);
 // PlyParser.parse (PlyParser.fs:65-69).
 bool parsePly(const std::string& text, std::vector<Triangle>& triangles, std::string& error);
+// Image.Load<Rgb24> (Textures/Image.fs:21-26) for local PNG / PPM files; ImageLoader.cpp.
+bool loadImageRgb24(const std::string& path, int& width, int& height, std::vector<uint8_t>& rgb, std::string& error);
 // Parsers.pcolour (SceneParser.fs:85-87), exposed for the reference's own colour tests.
 bool parseColour(const std::string& text, Colour& out);
 

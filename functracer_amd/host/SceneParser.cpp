@@ -170,7 +170,13 @@ struct Parser {
 
     Texture texture() {                                                                           // :159-185
         if (acceptCI("grid")) { anyWhitespace(); Texture t; t.kind = Texture::Grid; t.c1 = colour(); ws1(); t.c2 = colour(); return t; }
-        if (acceptCI("image")) { anyWhitespace(); Texture t; t.kind = Texture::Image; t.source = file(); return t; }
+        if (acceptCI("image")) {                                                                  // ImageTexture.image, Textures/Image.fs:20-36
+            anyWhitespace(); Texture t; t.kind = Texture::Image; t.source = file();
+            auto px = std::make_shared<std::vector<uint8_t>>(); std::string e;
+            if (!loadImageRgb24(resolvePath(t.source), t.width, t.height, *px, e)) throw ParseError{e};   // the reference raises while parsing too
+            t.pixels = px;
+            return t;
+        }
         if (peek() == '(') {
             ++i; anyWhitespace();
             TextureFunction f{};

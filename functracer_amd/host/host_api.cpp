@@ -77,10 +77,14 @@ struct Lowerer {
                         break;
                     }
                     case SceneFunction::TextureF: {
-                        if (f.texture.kind != Texture::Grid) { status = FT_ERR_UNSUPPORTED; return status; }   // image textures need files / HTTP (Textures/Image.fs)
-                        const double ca[3] = {f.texture.c1.r, f.texture.c1.g, f.texture.c1.b}, cb[3] = {f.texture.c2.r, f.texture.c2.g, f.texture.c2.b};
                         std::vector<double> ops;
                         for (auto& tf : f.texture.functions) { ops.push_back(tf.kind == TextureFunction::Scale ? 0.0 : 1.0); ops.push_back(tf.a); ops.push_back(tf.b); }
+                        if (f.texture.kind == Texture::Image) {
+                            if (!f.texture.pixels || !b->sg_texture_image) { status = FT_ERR_UNSUPPORTED; return status; }
+                            r = b->sg_texture_image(ctx, f.texture.pixels->data(), f.texture.width, f.texture.height, ops.data(), (int32_t)(ops.size() / 3), child);
+                            break;
+                        }
+                        const double ca[3] = {f.texture.c1.r, f.texture.c1.g, f.texture.c1.b}, cb[3] = {f.texture.c2.r, f.texture.c2.g, f.texture.c2.b};
                         r = b->sg_texture_grid(ctx, ca, cb, ops.data(), (int32_t)(ops.size() / 3), child);
                         break;
                     }
@@ -202,6 +206,15 @@ int64_t fth_parse_ply(const char* text, double* out, int64_t cap, char* err, int
         std::memcpy(out + 9 * i, v, sizeof v);
     }
     return (int64_t)tris.size();
+}
+
+int64_t fth_load_image(const char* path, int32_t* width, int32_t* height, uint8_t* out, int64_t cap, char* err, int32_t err_len) {
+    std::vector<uint8_t> rgb; std::string e; int w = 0, h = 0;
+    if (!path || !loadImageRgb24(path, w, h, rgb, e)) { put_err(err, err_len, e); return FT_ERR_INVALID; }
+    if (width) *width = w;
+    if (height) *height = h;
+    if (out && cap >= (int64_t)rgb.size()) std::memcpy(out, rgb.data(), rgb.size());
+    return (int64_t)rgb.size();
 }
 
 int32_t fth_jitter_pattern(uint64_t seed, int32_t n, double* out_xy) {

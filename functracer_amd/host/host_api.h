@@ -27,6 +27,7 @@ typedef struct fth_builder {
     ft_node (*sg_group)(void* ctx, const ft_node* children, int32_t n);
     ft_node (*sg_csg)(void* ctx, int32_t op, ft_node a, ft_node b);
     ft_node (*sg_texture_grid)(void* ctx, const double ca[3], const double cb[3], const double* uv_ops, int32_t n_uv_ops, ft_node child);
+    ft_node (*sg_texture_image)(void* ctx, const uint8_t* rgb24, int32_t width, int32_t height, const double* uv_ops, int32_t n_uv_ops, ft_node child);
     int32_t (*scene_clear)(void* ctx);
     int32_t (*scene_set_objects)(void* ctx, ft_node root);
     int32_t (*scene_add_directional)(void* ctx, const double dir[3], const double colour[3]);
@@ -55,6 +56,10 @@ int32_t fth_scene_lower(const fth_scene* s, const fth_builder* b, void* ctx);
 int32_t fth_parse_colour(const char* text, double rgb[3]);
 /* PlyParser.parse: returns triangle count (>= 0) and, when out != NULL, up to cap triangles (9 doubles each). */
 int64_t fth_parse_ply(const char* text, double* out, int64_t cap, char* err, int32_t err_len);
+
+/* Image.Load<Rgb24> for local PNG / PPM / PGM files (Textures/Image.fs:21-26).  Returns width*height*3 (bytes needed) and the
+ * size; fills out_rgb24 when cap is large enough.  Negative status + message on failure. */
+int64_t fth_load_image(const char* path, int32_t* width, int32_t* height, uint8_t* out_rgb24, int64_t cap, char* err, int32_t err_len);
 
 /* Jitter.pattern random Jitter.circle n (Jitter.fs:15-24) on a documented counter-based stream
  * (splitmix64 keyed by seed; uniform = 2*u - 1 with u = top 53 bits / 2^53) in place of the

@@ -148,9 +148,16 @@ ft_node ft_sg_hue_shift(ft_context* ctx, double angle, ft_node child);         /
 ft_node ft_sg_ignore_light(ft_context* ctx, ft_node child);                    /* Scene.fs:46     */
 ft_node ft_sg_group(ft_context* ctx, const ft_node* children, int32_t n);      /* Scene.fs:35     */
 ft_node ft_sg_csg(ft_context* ctx, int32_t op, ft_node a, ft_node b);          /* Scene.fs:36-39  */
-/* Scene.fs:44,47-53: Grid textures; Image textures are out of scope (need files/HTTP). */
+/* Scene.fs:44,47-53.  uv_ops: n x {kind, a, b}, outermost TextureFunction first: {0, sx, sy} = Scale, {1, radians, 0} =
+ * Rotate (Textures/Texture.fs:13-22); at most 5 per texture. */
 ft_node ft_sg_texture_grid(ft_context* ctx, const double colour_a[3], const double colour_b[3],
                            const double* uv_ops, int32_t n_uv_ops, ft_node child);
+/* Texture.Image (Scene.fs:48; ImageTexture.image, Textures/Image.fs:20-36).  The F# closure owns the decoded pixels;
+ * here the caller hands them over: rgb24 = image.SavePixelData() of an Image<Rgb24>, width*height*3 bytes, row 0 first
+ * (copied).  Lookup is the reference's nearest texel at index y*(3*width)+3*x with x = floor(u*width), y = floor(v*height)
+ * after Texture.repeat; an index past the last texel (where the reference raises) reads the last texel. */
+ft_node ft_sg_texture_image(ft_context* ctx, const uint8_t* rgb24, int32_t width, int32_t height,
+                            const double* uv_ops, int32_t n_uv_ops, ft_node child);
 
 /* ---- scene (Scene.fs:107-110, Light.fs:19-26) -------------------------------------------- */
 int32_t ft_scene_clear(ft_context* ctx);

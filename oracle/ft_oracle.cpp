@@ -114,6 +114,20 @@ Texture gridTexture(V3 c1, V3 c2) {                                             
         return c2;
     };
 }
+// ImageTexture.image (Textures/Image.fs:20-36): nearest texel of an Rgb24 image.  Where the reference would raise
+// IndexOutOfRange (index past the pixel array) the last texel is returned - the one stated deviation, shared with the device path.
+Texture imageTexture(std::shared_ptr<const std::vector<uint8_t>> pixels, int width, int height) {
+    return [pixels, width, height](double u0, double v0) {
+        double u = repeatOne(u0), v = repeatOne(v0);
+        double x = std::floor(u * (double)width), y = std::floor(v * (double)height);
+        double index = y * (3.0 * (double)width) + 3.0 * x;
+        double last = 3.0 * ((double)width * (double)height - 1.0);
+        if (!(index >= 0.0)) index = 0.0;
+        if (index > last) index = last;
+        size_t i = (size_t)index;
+        return V3{(double)(*pixels)[i] / 255.0, (double)(*pixels)[i + 1] / 255.0, (double)(*pixels)[i + 2] / 255.0};
+    };
+}
 
 // ---------------------------------------------------------------- Transform.fs
 struct M4 { double m[4][4]; };                                                   // Transform.fs:7-9
@@ -574,6 +588,7 @@ struct Node {
     Xf xf{Xf::Composed, {0, 0, 0}, 0.0, {}}; Material mat = mattWhite; int op = 0;
     std::vector<int> children;
     V3 ca{}, cb{}; std::vector<double> uvOps;
+    std::shared_ptr<const std::vector<uint8_t>> pixels; int imgW = 0, imgH = 0;      // Texture.Image
 };
 
 struct Counters { std::atomic<uint64_t> shadow{0}, reflect{0}; };
@@ -613,7 +628,7 @@ Geometry build(fto_context* ctx, int id) {                                      
         case Node::HueShift: return hueShift(build(ctx, n.children[0]));
         case Node::IgnoreLight: return ignoreLight(build(ctx, n.children[0]));
         case Node::Texture: {                                                    // Scene.fs:68-75
-            Texture tex = gridTexture(n.ca, n.cb);
+            Texture tex = n.pixels ? imageTexture(n.pixels, n.imgW, n.imgH) : gridTexture(n.ca, n.cb);
             // uvOps are listed outermost-first; each wraps the texture built so far from the inside out.
             for (int k = (int)n.uvOps.size() / 3 - 1; k >= 0; --k) {
                 int kind = (int)n.uvOps[3 * k]; double a = n.uvOps[3 * k + 1], b = n.uvOps[3 * k + 2];
@@ -801,6 +816,13 @@ ft_node fto_sg_group(fto_context* c, const ft_node* children, int32_t n) {
 ft_node fto_sg_csg(fto_context* c, int32_t op, ft_node a, ft_node b) {
     if (!validNode(c, a) || !validNode(c, b) || op < 0 || op > FT_CSG_EXCLUDE) return FT_ERR_INVALID;
     Node n; n.kind = Node::Csg; n.op = op; n.children = {a, b}; return newNode(c, std::move(n));
+}
+ft_node fto_sg_texture_image(fto_context* c, const uint8_t* rgb24, int32_t width, int32_t height, const double* uv_ops, int32_t n_uv_ops, ft_node child) {
+    if (!validNode(c, child) || !rgb24 || width <= 0 || height <= 0 || n_uv_ops < 0 || (n_uv_ops > 0 && !uv_ops)) return FT_ERR_INVALID;
+    Node n; n.kind = Node::Texture; n.ca = {0, 0, 0}; n.cb = {0, 0, 0};
+    n.pixels = std::make_shared<std::vector<uint8_t>>(rgb24, rgb24 + (size_t)width * height * 3); n.imgW = width; n.imgH = height;
+    n.uvOps.assign(uv_ops, uv_ops + 3 * n_uv_ops); n.children = {child};
+    return newNode(c, std::move(n));
 }
 ft_node fto_sg_texture_grid(fto_context* c, const double ca[3], const double cb[3], const double* uv_ops, int32_t n_uv_ops, ft_node child) {
     if (!validNode(c, child) || !ca || !cb || n_uv_ops < 0 || (n_uv_ops > 0 && !uv_ops)) return FT_ERR_INVALID;

@@ -51,6 +51,8 @@ ft_node fto_sg_group(fto_context* ctx, const ft_node* children, int32_t n);
 ft_node fto_sg_csg(fto_context* ctx, int32_t op, ft_node a, ft_node b);
 ft_node fto_sg_texture_grid(fto_context* ctx, const double colour_a[3], const double colour_b[3],
                             const double* uv_ops, int32_t n_uv_ops, ft_node child);
+ft_node fto_sg_texture_image(fto_context* ctx, const uint8_t* rgb24, int32_t width, int32_t height,
+                             const double* uv_ops, int32_t n_uv_ops, ft_node child);
 
 int32_t fto_scene_clear(fto_context* ctx);
 int32_t fto_scene_set_objects(fto_context* ctx, ft_node root);

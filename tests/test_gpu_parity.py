@@ -136,7 +136,7 @@ def test_triangle_primitives_as_group(hip):
     H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="triangle group")
 
 
-SMALL = [("sample-det", 96, 96, 2), ("hollow-sphere", 160, 90, 1), ("bunny", 160, 90, 4), ("bunny-bsp12", 160, 90, 2), ("night-house-det", 160, 90, 3)]
+SMALL = [("moon", 200, 200, 1), ("sample-det", 96, 96, 2), ("hollow-sphere", 160, 90, 1), ("bunny", 160, 90, 4), ("bunny-bsp12", 160, 90, 2), ("night-house-det", 160, 90, 3)]
 
 
 def _load(name):
@@ -417,3 +417,27 @@ def test_unclipped_bvh_fast_mode_stays_within_the_contract(hip):
     # triangle disagree about a grazing hit.  That is why the mode is opt-in and not the parity path.
     assert moved <= 0.005 * err.shape[0] * err.shape[1], moved
     assert np.median(err) < 1e-12
+
+
+def test_image_textures_match_oracle(hip):
+    """Texture.Image under uv functions, hueShift and ignoreLight (the sky-sphere use of Scenes/sample.scene:6)."""
+    rng = np.random.default_rng(11)
+    sky = rng.integers(0, 256, size=(32, 64, 3), dtype=np.uint8)
+    tile = rng.integers(0, 256, size=(5, 7, 3), dtype=np.uint8)          # odd sizes: u*width is rarely exact
+    orc = O.Oracle()
+    for b in (orc, hip):
+        b.clear()
+        dome = b.ignore_light(b.texture_image(sky, [], b.scale(40, b.primitive(ft.SPHERE))))
+        floor = b.texture_image(tile, [(0, 0.7, 1.3), (1, 0.4, 0.0)], b.translate((0, -1, 0), b.primitive(ft.PLANE)))
+        ball = b.hue_shift(0.0, b.texture_image(tile, [(1, -1.1, 0.0)], b.material(b.primitive(ft.SPHERE), colour=(1, 1, 1), reflectance=0.3, shineyness=20)))
+        b.set_objects(b.group([dome, floor, ball]))
+        b.add_directional((-1, -2, 1.5), (1, 1, 1))
+        b.add_positional((2, 3, -2), (1, 0.05, 0.01), (0.8, 0.7, 0.6))
+        b.commit()
+    o, d = H.random_rays(20000, seed=33, origin_scale=2.5, toward=(0, 0, 0), spread=2.0)
+    H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="image textures")
+    cam = ft.make_camera((0, 1.5, -5), (0, 0, 0), (0, 1, 0), H.deg(60.0))
+    jit = ft.jitter_pattern(2)
+    want, _ = orc.render(cam, 160, 120, 2, jit)
+    got, _ = hip.render(cam, 160, 120, 2, jit)
+    assert H.assert_frames_match(got, want, what="image textures") < 1e-6

@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: the .scene / PLY loaders, scene flattening and the product's
 own BSP builder (through the host-only test hook of the C ABI), and the exported ABI surface."""
 import ctypes as C
+import math
 import os
 import re
 
@@ -140,8 +141,12 @@ def test_unsupported_surface_is_rejected_loudly():
     with pytest.raises(ft.FtError) as e:
         ctx.commit()
     assert e.value.status == -4 and "texture" in str(e.value)
-    with pytest.raises(ft.FtError):                           # image textures need files / HTTP: refused by the lowering (FT_ERR_UNSUPPORTED)
-        ft.parse_scene('(texture image "x.jpg" sphere)\n').lower(ctx)
+    with pytest.raises(ValueError) as e:                      # like the reference, a texture that cannot be loaded fails the parse
+        ft.parse_scene('(texture image "no-such-file.png" sphere)\n')
+    assert "cannot open image file" in str(e.value)
+    with pytest.raises(ValueError) as e:                      # Textures/Image.fs:11-13 fetches URLs; there is no network here
+        ft.parse_scene('(texture image "http://example.invalid/moon.jpg" sphere)\n')
+    assert "URL" in str(e.value)
     with pytest.raises(ft.FtError):
         ctx.primitive(99)
     with pytest.raises(ft.FtError):
@@ -183,3 +188,64 @@ def test_png_writer_roundtrip(tmp_path):
     path = tmp_path / "x.png"
     ft.write_png(path, rgba)
     assert np.array_equal(np.asarray(Image.open(path).convert("RGBA")), rgba)
+
+
+def test_image_loader_formats(tmp_path):                      # harness counterpart of Image.Load<Rgb24> (Textures/Image.fs:21-24)
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, size=(13, 17, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "rgb.png")                                   # PIL picks adaptive filters per row
+    assert np.array_equal(ft.load_image(tmp_path / "rgb.png"), rgb)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, size=(13, 17, 1), dtype=np.uint8)], -1)
+    Image.fromarray(rgba).save(tmp_path / "rgba.png")                                 # alpha is dropped
+    assert np.array_equal(ft.load_image(tmp_path / "rgba.png"), rgb)
+    grey = rng.integers(0, 256, size=(9, 11), dtype=np.uint8)
+    Image.fromarray(grey).save(tmp_path / "grey.png")
+    assert np.array_equal(ft.load_image(tmp_path / "grey.png"), np.repeat(grey[..., None], 3, -1))
+    pal = Image.fromarray(rgb).quantize(colors=7)                                     # 4-bit palette image
+    pal.save(tmp_path / "pal.png", bits=4)
+    assert np.array_equal(ft.load_image(tmp_path / "pal.png"), np.asarray(pal.convert("RGB")))
+    bw = Image.fromarray(grey > 127)                                                  # 1-bit grey
+    bw.save(tmp_path / "bw.png")
+    assert np.array_equal(ft.load_image(tmp_path / "bw.png"), np.repeat((np.asarray(bw) * 255).astype(np.uint8)[..., None], 3, -1))
+    Image.fromarray(rgb).save(tmp_path / "rgb.ppm")
+    assert np.array_equal(ft.load_image(tmp_path / "rgb.ppm"), rgb)
+    (tmp_path / "ascii.ppm").write_text("P3\n# comment\n2 1\n255\n1 2 3  250 251 252\n")
+    assert ft.load_image(tmp_path / "ascii.ppm").tolist() == [[[1, 2, 3], [250, 251, 252]]]
+    Image.fromarray(rgb).save(tmp_path / "x.jpg")
+    with pytest.raises(ft.FtError) as e:
+        ft.load_image(tmp_path / "x.jpg")
+    assert "JPEG" in str(e.value)
+    bad = bytearray((tmp_path / "rgb.png").read_bytes())
+    bad[40] ^= 0xFF                                                                   # corrupt the IDAT body: CRC check refuses it
+    (tmp_path / "bad.png").write_bytes(bad)
+    with pytest.raises(ft.FtError):
+        ft.load_image(tmp_path / "bad.png")
+
+
+def test_committed_texture_png_is_what_the_tool_writes():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_texture_png", os.path.join(H.ROOT, "tools", "make_texture_png.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    img = ft.load_image(os.path.join(H.ROOT, "scenes", "textures", "moon_synth_256x128.png"))   # rows use all five PNG filters
+    assert np.array_equal(img, m.moon(256, 128, 1969))
+
+
+def test_image_texture_lookup_follows_the_reference_index_rule():       # Textures/Image.fs:27-35
+    img = np.arange(4 * 3 * 3, dtype=np.uint8).reshape(3, 4, 3) * 7      # height 3, width 4
+    orc = O.Oracle()
+    orc.clear()
+    # Plane.fs:28-33 gives uv = (x, z) of the model-space hit point on the plane y = 0.
+    orc.set_objects(orc.group([orc.texture_image(img, [], orc.primitive(ft.PLANE))]))
+    orc.add_directional((0, -1, 0), (1, 1, 1))
+    orc.commit()
+    pts = np.array([[0.1, 0.1], [0.3, 0.1], [0.99, 0.9], [1.6, 0.4], [-0.2, 2.5], [0.5, 0.5]])
+    o = np.column_stack([pts[:, 0], np.full(len(pts), 2.0), pts[:, 1]])
+    d = np.tile([0.0, -1.0, 0.0], (len(pts), 1))
+    hit, t, p, n, c = orc.closest(o, d)
+    assert hit.all()
+    for (u, v), got in zip(pts, c):
+        ru, rv = abs(u - math.floor(u)), abs(v - math.floor(v))          # Texture.repeat
+        x, y = math.floor(ru * 4), math.floor(rv * 3)
+        assert np.allclose(got, img[y, x] / 255.0, rtol=0, atol=0), (u, v)
