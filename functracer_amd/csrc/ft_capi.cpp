@@ -566,7 +566,8 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         const uint32_t n_samples = n_pix * (uint32_t)spp;
         timed(0, [&] { (void)hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream); });
         const ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
-                               (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed};
+                               (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
+                               1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h)};
         for (int b = 0; b <= last_bounce; ++b) {
             timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, cc, rcount); });
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });

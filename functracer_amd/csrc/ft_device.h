@@ -81,6 +81,7 @@ struct Primary {
     int32_t spp;
     uint32_t stride;               // ids are y*stride + x: res_h for pixels, res_h + 1 for the corner grid of `samples corner`
     unsigned long long seed;       // keys the counter-based streams of soft shadows / depth of field
+    double inv_n_pix, inv_stride;  // 1.0 / n_pix, 1.0 / stride (division-free index arithmetic, see div_by)
 };
 // K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.  Bounce 0 also records, one
 // byte per sample, whether the primary ray hit anything (`touched`): untouched samples are Colour.Zero and their accumulator is

@@ -47,6 +47,26 @@ template <class T> FT_DEV const FT_CONST T* to_const_as(const T* p) {
     return (const FT_CONST T*)p;
 #pragma clang diagnostic pop
 }
+// Launch arguments are read where they are used, through the kernarg segment (constant address space, scalar loads),
+// instead of living in SGPRs for the whole kernel: with ~60 SGPRs of camera / buffer pointers held across the scene
+// interpreter every kernel ran out of scalar registers and the compiler parked them in VGPR lanes (v_writelane /
+// v_readlane - VALU instructions - by the hundred per batch).  `fresh()` returns the same pointer behind an opaque
+// zero so that loads through it cannot be hoisted out of the batch loop and stay short-lived.
+FT_DEV uint32_t opaque_zero() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
+template <class T> FT_DEV const FT_CONST T* kernel_args() {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const FT_CONST T*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma clang diagnostic pop
+}
+template <class T> FT_DEV const FT_CONST T* fresh(const FT_CONST T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const FT_CONST T*)((const FT_CONST char*)p + opaque_zero());
+#pragma clang diagnostic pop
+}
+typedef const FT_CONST Primary* PrimaryArg;
+
 struct Scene {
     cdp leaves;       // 16 doubles per leaf (ftd::Leaf)
     cdp m2w;          // 12 per leaf
@@ -64,7 +84,7 @@ struct Scene {
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
 };
 static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
-FT_DEV Scene scene_view(const DevScene& g) {
+template <class DS> FT_DEV Scene scene_view(const DS& g) {
     Scene s;
     s.leaves = to_const_as(g.leaves); s.m2w = to_const_as(g.m2w);
     s.materials = to_const_as(reinterpret_cast<const double*>(g.materials)); s.lights = to_const_as(reinterpret_cast<const double*>(g.lights));
@@ -834,47 +854,60 @@ struct JitterFrame {
         return normalise(V3{(nv.x + a * i.x) + b * j.x, (nv.y + a * i.y) + b * j.y, (nv.z + a * i.z) + b * j.z});
     }
 };
-FT_DEV unsigned long long sample_id(const Primary& g, uint32_t slot) {
-    const uint32_t s = slot / g.n_pix, pl = slot - s * g.n_pix;
-    return (unsigned long long)g.pixel_ids[g.pix_base + pl] * (unsigned long long)g.spp + s;
+// a / b for the two divisors of a launch (pixels per chunk, row stride) through the divisor's reciprocal: exact, because
+// (a + 0.5) / b is at least 0.5 / b away from every integer while the product's rounding error is below quotient * 2^-51
+// and quotient * b < 2^32 (four FP64 instructions in place of the ~25 of an integer division).
+FT_DEV uint32_t div_by(uint32_t a, double inv_b) { return (uint32_t)(((double)a + 0.5) * inv_b); }
+
+FT_DEV unsigned long long sample_id(PrimaryArg g, uint32_t slot) {
+    const uint32_t s = div_by(slot, g->inv_n_pix), pl = slot - s * g->n_pix;
+    return (unsigned long long)g->pixel_ids[g->pix_base + pl] * (unsigned long long)g->spp + s;
 }
 
 // Primary rays are never stored: bounce 0 of k_closest / k_shade regenerates them from the sample index
 // (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
 // 64 pixels of one 8x8 block for one jitter offset).
-FT_DEV uint32_t primary_pixel(const Primary& g, uint32_t i) {        // the one memory access a primary ray needs
-    const uint32_t s = i / g.n_pix, pl = i - s * g.n_pix;
-    return g.pixel_ids[g.pix_base + pl];
+FT_DEV uint32_t primary_pixel(PrimaryArg g, uint32_t i) {            // the one memory access a primary ray needs
+    const uint32_t s = div_by(i, g->inv_n_pix), pl = i - s * g->n_pix;
+    return g->pixel_ids[g->pix_base + pl];
 }
 // `uniform_s`: all 64 lanes of the batch share one jitter offset (n_pix is a multiple of 64): it is then read
 // through a scalar load, which does not queue behind the wave's outstanding vector stores.
-FT_DEV Ray primary_ray_from(const Primary& g, uint32_t i, uint32_t pid, bool uniform_s) {
-    const uint32_t s = i / g.n_pix;
-    const uint32_t py = pid / g.stride, px = pid - py * g.stride;
-    const double centre_x = g.cam.tlx + (double)px * g.cam.pw, centre_y = g.cam.tly - (double)py * g.cam.ph;
+FT_DEV Ray primary_ray_from(PrimaryArg g, uint32_t i, uint32_t pid, bool uniform_s) {
+    const uint32_t s = div_by(i, g->inv_n_pix);
+    const uint32_t py = div_by(pid, g->inv_stride), px = pid - py * g->stride;
+    const double centre_x = g->cam.tlx + (double)px * g->cam.pw, centre_y = g->cam.tly - (double)py * g->cam.ph;
     double ox, oy;
-    if (uniform_s) { cdp J = to_const_as(g.jitter) + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)s); ox = J[0]; oy = J[1]; }
-    else { ox = g.jitter[2 * s]; oy = g.jitter[2 * s + 1]; }
-    const double jx = centre_x + ox * g.cam.pw, jy = centre_y + oy * g.cam.ph;
-    Ray r{g.cam.o[0], g.cam.o[1], g.cam.o[2],
-          (g.cam.k[0] + jx * g.cam.i[0]) + jy * g.cam.j[0], (g.cam.k[1] + jx * g.cam.i[1]) + jy * g.cam.j[1], (g.cam.k[2] + jx * g.cam.i[2]) + jy * g.cam.j[2]};
-    if (g.cam.has_focus) {                                         // ImagePlane.depthOfFieldJitter (Image.fs:91-94, Ray.fs:15-18)
-        Rng rng = make_rng(g.seed, (unsigned long long)pid * (unsigned long long)g.spp + s, 0u, 0u, 2u);
-        const double f = g.cam.focal_length;
+    if (uniform_s) { cdp J = to_const_as(g->jitter) + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)s); ox = J[0]; oy = J[1]; }
+    else { ox = g->jitter[2 * s]; oy = g->jitter[2 * s + 1]; }
+    const double jx = centre_x + ox * g->cam.pw, jy = centre_y + oy * g->cam.ph;
+    Ray r{g->cam.o[0], g->cam.o[1], g->cam.o[2],
+          (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0], (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1], (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2]};
+    if (g->cam.has_focus) {                                         // ImagePlane.depthOfFieldJitter (Image.fs:91-94, Ray.fs:15-18)
+        Rng rng = make_rng(g->seed, (unsigned long long)pid * (unsigned long long)g->spp + s, 0u, 0u, 2u);
+        const double f = g->cam.focal_length;
         const V3 o1{r.ox + f * r.dx, r.oy + f * r.dy, r.oz + f * r.dz};                               // shiftOrigin focalLength
-        const V3 d1 = JitterFrame(V3{r.dx, r.dy, r.dz}, g.cam.tan_half_aperture).jittered(rng);        // jitterDirection
+        const V3 d1 = JitterFrame(V3{r.dx, r.dy, r.dz}, g->cam.tan_half_aperture).jittered(rng);        // jitterDirection
         r = {o1.x + -f * d1.x, o1.y + -f * d1.y, o1.z + -f * d1.z, d1.x, d1.y, d1.z};                  // shiftOrigin -focalLength
     }
     return r;
 }
-FT_DEV Ray primary_ray(const Primary& g, uint32_t i) { return primary_ray_from(g, i, primary_pixel(g, i), false); }
+FT_DEV Ray primary_ray(PrimaryArg g, uint32_t i) { return primary_ray_from(g, i, primary_pixel(g, i), false); }
+
+struct ClosestArgs {
+    DevScene S; Primary gen; RayBuf rays; HitBuf hits;
+    uint32_t* hit_list; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc; int32_t bounce;
+};
 
 template <bool MESH>
-__global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, uint32_t* __restrict__ hit_list, uint8_t* __restrict__ touched, int bounce,
-                                                     ChunkCounters* cc, RenderCounters* rc) {
+__global__ __launch_bounds__(kBlock, 4) void k_closest(ClosestArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const Scene S = scene_view(Sg);
-    const uint32_t n = bounce == 0 ? gen.n_pix * (uint32_t)gen.spp : cc->n_rays[bounce];
+    const FT_CONST ClosestArgs* K = kernel_args<ClosestArgs>();
+    const Scene S = scene_view(K->S);
+    const int bounce = K->bounce;
+    ChunkCounters* cc = K->cc;
+    const uint32_t n_pix = K->gen.n_pix;
+    const uint32_t n = bounce == 0 ? n_pix * (uint32_t)K->gen.spp : cc->n_rays[bounce];
     const uint32_t B = batch_lanes_for(n);
     const uint32_t n_batches = (n + B - 1) / B;
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
@@ -883,8 +916,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
     uint32_t mask_lo = 0, mask_hi = 0, base_of = 0, pending = 0, pending_hits = 0;
     auto flush = [&]() {
         if (pending_hits) {
+            const FT_CONST ClosestArgs* Kf = fresh(K);
+            uint32_t* hit_list = Kf->hit_list;
             uint32_t dst = 0;
-            if (lane_id() == 0) dst = atomicAdd(&cc->n_hits[bounce], pending_hits);
+            if (lane_id() == 0) dst = atomicAdd(&Kf->cc->n_hits[bounce], pending_hits);
             dst = __builtin_amdgcn_readfirstlane(dst);
             for (uint32_t k = 0; k < pending; ++k) {
                 const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_lo, (int)k) |
@@ -900,29 +935,35 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
     // Vector memory operations of a wave complete in issue order, so a load issued after the previous batch's stores
     // would wait for those stores to be acknowledged: the pixel id of the wave's NEXT batch is requested before the
     // current one is traced and stored.
-    const bool uniform_s = bounce == 0 && B == 64u && (gen.n_pix & 63u) == 0u;
+    const bool uniform_s = bounce == 0 && B == 64u && (n_pix & 63u) == 0u;
     BatchCursor cursor(&cc->work_trace[bounce][0]);
     uint32_t bi = cursor.grab(), bi_next = cursor.grab();           // two deep: the index after next is in flight while this batch runs
     uint32_t pid_next = 0;
-    if (bounce == 0 && bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(gen, bi * B + lane_id());
+    if (bounce == 0 && bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, bi * B + lane_id());
     for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
         const uint32_t base = bi * B;
         const uint32_t i = base + lane_id();
         const uint32_t pid = pid_next;
-        if (bounce == 0 && bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(gen, bi_next * B + lane_id());
         Query<false> q;
         q.active = i < n && lane_id() < B; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
         Ray r{0, 0, 0, 0, 0, 0};
-        if (q.active) {
-            if (bounce == 0) r = primary_ray_from(gen, i, pid, uniform_s);
-            else r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
-            r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
+        {
+            const FT_CONST ClosestArgs* Kb = fresh(K);              // camera, pixel list, ray buffers: loaded here, dead before the trace
+            if (bounce == 0 && bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, bi_next * B + lane_id());
+            if (q.active) {
+                if (bounce == 0) r = primary_ray_from(&Kb->gen, i, pid, uniform_s);
+                else { const FT_CONST RayBuf& rays = Kb->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; }
+                r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
+            }
         }
         bool overflow;
         trace<false, MESH>(S, r, q, lds, overflow, bounce == 0);   // primary rays of one pixel block walk meshes as a packet
         const bool hit = q.active && q.id0 != ID_MISS;
-        if (hit) { hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }   // only rays that hit are ever looked at again
-        if (bounce == 0 && q.active) touched[i] = hit ? 1 : 0;      // samples whose primary ray misses stay Colour.Zero: never stored, never read
+        {
+            const FT_CONST ClosestArgs* Ke = fresh(K);
+            if (hit) { const FT_CONST HitBuf& hits = Ke->hits; hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }   // only rays that hit are ever looked at again
+            if (bounce == 0 && q.active) Ke->touched[i] = hit ? 1 : 0;   // samples whose primary ray misses stay Colour.Zero: never stored, never read
+        }
         const unsigned long long m = __ballot(hit);
         if (m) {
             if (lane_id() == pending) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); base_of = base; }
@@ -932,7 +973,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
         n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
     }
     flush();
-    RenderCounters* mine = my_stats(rc);
+    RenderCounters* mine = my_stats(fresh(K)->rc);
     if (bounce == 0) wave_add(&mine->hits_primary, n_hit_wave);
     wave_add(&mine->csg_overflow, n_ovf_wave);
 }
@@ -943,12 +984,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_closest(DevScene Sg, Primary gen,
 // Two passes over the lights keep the live state across the shadow traces small (p, n and a few words instead
 // of the whole fragment state): pass 1 only decides visibility (one byte per light: occluded sample count),
 // pass 2 reloads the ray and the material and evaluates the shaders.
+struct ShadeArgs {
+    DevScene S; Primary gen; RayBuf rays; HitBuf hits; RayBuf next;
+    const uint32_t* hit_list; double* acc; ChunkCounters* cc; RenderCounters* rc;
+    uint32_t acc_stride; int32_t bounce, max_depth;
+};
+
 template <bool FANCY, bool SOFT, bool MESH>
-__global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Primary gen, RayBuf rays, HitBuf hits, const uint32_t* __restrict__ hit_list, RayBuf next,
-                                                   double* __restrict__ acc, uint32_t acc_stride, int bounce, int max_depth,
-                                                   ChunkCounters* cc, RenderCounters* rc) {
+__global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(ShadeArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const Scene S = scene_view(Sg);
+    const FT_CONST ShadeArgs* K = kernel_args<ShadeArgs>();
+    const Scene S = scene_view(K->S);
+    const int bounce = K->bounce;
+    ChunkCounters* cc = K->cc;
     const uint32_t n = cc->n_hits[bounce];
     const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
@@ -964,16 +1012,18 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
         bool lit = false;
         unsigned long long sample = 0ull;
         if (active) {
-            const uint32_t i = hit_list[j];
+            const FT_CONST ShadeArgs* Kb = fresh(K);                // buffers and camera: loaded here, dead before the shadow traces
+            const uint32_t i = Kb->hit_list[j];
             Ray r;
             uint32_t slot;
-            if (bounce == 0) { r = primary_ray(gen, i); slot = i; }
-            else { r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; slot = rays.slot[i]; }
+            if (bounce == 0) { r = primary_ray(&Kb->gen, i); slot = i; }
+            else { const FT_CONST RayBuf& rays = Kb->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; slot = rays.slot[i]; }
+            const FT_CONST HitBuf& hits = Kb->hits;
             // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
             const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
             sf = surface_at<FANCY>(S, ro, hits.t[i], hits.id0[i], hits.id1[i]);
             lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
-            if (SOFT) sample = sample_id(gen, slot);
+            if (SOFT) sample = sample_id(&Kb->gen, slot);
         }
         unsigned long long vis_lo = 0ull, vis_hi = 0ull;           // byte l = occluded shadow samples of light l
         for (int l = 0; l < n_lights; ++l) {                       // wave-uniform; getLightsOnPoint (Shading.fs:109-117)
@@ -985,7 +1035,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
             if (SOFT && kind == LT_SOFT) {                         // softShadowLightIntensity (Shading.fs:24-31)
                 const int samples = reinterpret_cast<cip>(lp + 10)[1];
                 const JitterFrame frame(V3{-lp[0], -lp[1], -lp[2]}, lp[11]);
-                Rng rng = make_rng(gen.seed, sample, (uint32_t)bounce, (uint32_t)l, 1u);
+                Rng rng = make_rng(fresh(K)->gen.seed, sample, (uint32_t)bounce, (uint32_t)l, 1u);
                 for (int k = 0; k < samples; ++k) {                // wave-uniform count; each lane draws its own direction
                     const V3 dj = frame.jittered(rng);
                     Query<true> qs;
@@ -1019,10 +1069,11 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
         // ---------------- pass 2: the shaders (Shading.fs:50-107) with everything reloaded ------------------
         Ray r{0, 0, 0, 0, 0, 0};
         double w = 0.0; uint32_t slot = 0;
+        const FT_CONST ShadeArgs* K2 = fresh(K);
         if (active) {
-            const uint32_t i = hit_list[j];
-            if (bounce == 0) { r = primary_ray(gen, i); w = 1.0; slot = i; }
-            else { r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i]; }
+            const uint32_t i = K2->hit_list[j];
+            if (bounce == 0) { r = primary_ray(&K2->gen, i); w = 1.0; slot = i; }
+            else { const FT_CONST RayBuf& rays = K2->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i]; }
         }
         MaterialV mat = material_at(S, sf.material);               // per-lane gather (64 B records, L1/L2 resident)
         if (FANCY) { if (active && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }   // Ray.textureDiffuse (Ray.fs:57-59)
@@ -1074,6 +1125,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
             cr += fr; cg += fg; cb += fb;
         }
         if (active) {                                              // one ray per sample per bounce: no write conflicts, fixed order
+            double* acc = K2->acc; const uint32_t acc_stride = K2->acc_stride;
             if (bounce == 0) {                                     // first contribution of the sample: 0 + x = x, so a plain store replaces clear + add
                 acc[slot] = w * cr; acc[(size_t)acc_stride + slot] = w * cg; acc[2 * (size_t)acc_stride + slot] = w * cb;
             } else {
@@ -1083,14 +1135,15 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
         // reflectionShader (Shading.fs:89-98): every one of the L fragments adds reflectance * colour(reflected ray);
         // those L sub-traces are identical (deterministic lights, or streams keyed without the parent light), so one
         // ray carries weight L * reflectance.
-        const bool spawn = lit && mat.reflectance > 0.0 && bounce < max_depth;
+        const bool spawn = lit && mat.reflectance > 0.0 && bounce < K2->max_depth;
         const unsigned long long m = __ballot(spawn);
         const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t dst = 0;
-        if (lane_id() == 0 && cnt) dst = atomicAdd(&cc->n_rays[bounce + 1], cnt);
+        if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->cc->n_rays[bounce + 1], cnt);
         dst = __builtin_amdgcn_readfirstlane(dst);
         if (spawn) {
             const uint32_t o = dst + lanes_below(m);
+            const FT_CONST RayBuf& next = K2->next;
             const double k2 = 2.0 * dot3(r.dx, r.dy, r.dz, sf.n.x, sf.n.y, sf.n.z);
             next.ox[o] = sf.p.x; next.oy[o] = sf.p.y; next.oz[o] = sf.p.z;
             next.dx[o] = r.dx - k2 * sf.n.x; next.dy[o] = r.dy - k2 * sf.n.y; next.dz[o] = r.dz - k2 * sf.n.z;
@@ -1100,7 +1153,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
         n_refl_wave += cnt;
         n_hit_wave += (unsigned long long)__popcll(__ballot(active));
     }
-    RenderCounters* mine = my_stats(rc);
+    RenderCounters* mine = my_stats(fresh(K)->rc);
     wave_add(&mine->rays_shadow, n_shadow_wave);
     wave_add(&mine->rays_reflect, n_refl_wave);
     wave_add(&mine->hits_total, n_hit_wave);
@@ -1109,7 +1162,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(DevScene Sg, Pr
     // and each reflective hit L reflection rays (Shading.fs:109-139).
     if (lane_id() == 0 && (n_hit_wave || n_refl_wave)) {
         const double mult = pow((double)n_lights, (double)bounce);
-        mine->ref_equiv += mult * ((double)Sg.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
+        mine->ref_equiv += mult * ((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
     }
 }
 
@@ -1206,7 +1259,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
 
 } // namespace
 
-typedef void (*ShadeKernel)(DevScene, Primary, RayBuf, HitBuf, const uint32_t*, RayBuf, double*, uint32_t, int, int, ChunkCounters*, RenderCounters*);
+typedef void (*ShadeKernel)(ShadeArgs);
 static ShadeKernel shade_variant(int v) {                          // bit 0 FANCY, bit 1 SOFT, bit 2 MESH
     switch (v & 7) {
         case 0: return k_shade<false, false, false>;
@@ -1224,13 +1277,15 @@ static ShadeKernel shade_variant(int v) {                          // bit 0 FANC
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
 void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, ChunkCounters* cc, RenderCounters* rc) {
-    if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, touched, bounce, cc, rc);
-    else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, touched, bounce, cc, rc);
+    const ClosestArgs a{S, gen, rays, hits, hit_list, touched, cc, rc, bounce};
+    if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
+    else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
                   uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
     auto k = shade_variant(L.variant);
-    hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, S, gen, rays, hits, hit_list, next, acc, acc_stride, bounce, max_depth, cc, rc);
+    const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, cc, rc, acc_stride, bounce, max_depth};
+    hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
 void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, spp, out_index, out_rgb);
