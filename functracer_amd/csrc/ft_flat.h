@@ -109,8 +109,13 @@ enum Op : uint32_t {
     OP_FOLD_LIST = 5,      // fold the per-lane list into closest / any-hit and clear it
     OP_CULL = 6,           // arg = cull record; next word = number of program words of the item that follows.
                            // If no lane of the wave can possibly hit the item, the item is skipped.
-    OP_SKIP_IF_EMPTY = 7   // after operand A of subtract / intersect: if no lane has an A hit the result is empty for
+    OP_SKIP_IF_EMPTY = 7,  // after operand A of subtract / intersect: if no lane has an A hit the result is empty for
                            // every lane (Csg.fs:27-44 never Take/Flip a B hit while outside A), so pop A's mark and skip arg words
+    OP_CSG_PAIR = 8        // a CSG node over two bare primitives, merged in registers.  arg = words of the generic sequence
+                           // (MARK, LEAF_PUSH A, ..., CSG[, FOLD_LIST]) that follows the two operand words
+                           //   word 1 = leaf A;  word 2 = leaf B | op << 24 | fold << 26 (fold: top level, result goes to the query)
+                           // and is skipped when the fast path applies to every lane of the wave (each operand gave at most two
+                           // hits, none NaN); otherwise execution simply continues into the generic sequence.
 };
 
 // Conservative bound of one top-level item (a leaf or an outermost CSG subtree), 24 doubles.

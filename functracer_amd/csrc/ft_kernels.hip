@@ -657,6 +657,58 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                 if (!__any(need)) pc += S.program[pc];
                 break;
             }
+            case OP_CSG_PAIR: {
+                // Csg.constructedSolid (Csg.fs:74-94) over two bare primitives with the hit lists in registers.  The
+                // stable sort of [A hits; B hits] by t is the merge of the two (stably sorted) operands with ties to A.
+                const uint32_t leaf_a = S.program[pc + 1], wb = S.program[pc + 2];
+                const uint32_t leaf_b = wb & ID_LEAF_MASK, cop = (wb >> 24) & 3u;
+                const bool fold = ((wb >> 26) & 1u) != 0;
+                pc += 2;
+                struct Two { double t0, t1; uint32_t s0, s1; int n; };
+                Two A{0.0, 0.0, 0u, 0u, 0}, Bh{0.0, 0.0, 0u, 0u, 0};
+                const LeafHead HA = leaf_head(S, leaf_a);
+                leaf_hits<false>(S, leaf_a, HA, r, q.active, stack, [&](double t, uint32_t sub, uint32_t) {
+                    if (q.active) { if (A.n == 0) { A.t0 = t; A.s0 = sub; } else if (A.n == 1) { A.t1 = t; A.s1 = sub; } ++A.n; } });
+                if ((cop == 1u || cop == 2u) && !__any(A.n > 0)) { pc += arg; break; }    // intersect / subtract with no A hit: empty (Csg.fs:27-44)
+                const LeafHead HB = leaf_head(S, leaf_b);
+                leaf_hits<false>(S, leaf_b, HB, r, q.active, stack, [&](double t, uint32_t sub, uint32_t) {
+                    if (q.active) { if (Bh.n == 0) { Bh.t0 = t; Bh.s0 = sub; } else if (Bh.n == 1) { Bh.t1 = t; Bh.s1 = sub; } ++Bh.n; } });
+                const bool odd = A.n > 2 || Bh.n > 2 || (A.n > 0 && A.t0 != A.t0) || (A.n > 1 && A.t1 != A.t1) || (Bh.n > 0 && Bh.t0 != Bh.t0) || (Bh.n > 1 && Bh.t1 != Bh.t1);
+                if (__any(odd)) break;                             // rare (parallel-ray hits of Plane.fs:13-16, NaN): the generic sequence follows
+                pc += arg;
+                if (!__any(A.n + Bh.n > 0)) break;
+                if (A.n == 2 && A.t1 < A.t0) { const double t = A.t0; A.t0 = A.t1; A.t1 = t; const uint32_t u = A.s0; A.s0 = A.s1; A.s1 = u; }
+                if (Bh.n == 2 && Bh.t1 < Bh.t0) { const double t = Bh.t0; Bh.t0 = Bh.t1; Bh.t1 = t; const uint32_t u = Bh.s0; Bh.s0 = Bh.s1; Bh.s1 = u; }
+                uint32_t take, flip;
+                switch (cop) {                                      // rule tables as in csg_merge
+                    case 0: take = 0xC3u; flip = 0x00u; break;
+                    case 1: take = 0x3Cu; flip = 0x00u; break;
+                    case 2: take = 0x41u; flip = 0x28u; break;
+                    default: take = 0xC3u; flip = 0x3Cu; break;
+                }
+                const uint32_t tag_a = leaf_a | ((HA.flags & LF_LIT) ? ID_LIT : 0u), tag_b = leaf_b | ((HB.flags & LF_LIT) ? ID_LIT : 0u);
+                int ia = 0, ib = 0;
+                bool in_a = false, in_b = false;
+#pragma unroll
+                for (int step = 0; step < 4; ++step) {
+                    const bool has_a = ia < A.n, has_b = ib < Bh.n;
+                    if (!__any(has_a || has_b)) break;
+                    const double ta = ia == 0 ? A.t0 : A.t1, tb = ib == 0 ? Bh.t0 : Bh.t1;
+                    const bool side_b = has_b && (!has_a || tb < ta);
+                    const double t = side_b ? tb : ta;
+                    uint32_t id0 = side_b ? (tag_b | ((ib == 0 ? Bh.s0 : Bh.s1) << ID_SUB_SHIFT)) : (tag_a | ((ia == 0 ? A.s0 : A.s1) << ID_SUB_SHIFT));
+                    const uint32_t type = (0x53714620u >> (4 * ((side_b ? 4 : 0) + (in_a ? 2 : 0) + (in_b ? 1 : 0)))) & 0xF;
+                    if (has_a || has_b) {
+                        if (side_b) { in_b = !in_b; ++ib; } else { in_a = !in_a; ++ia; }
+                        if ((flip >> type) & 1u) id0 ^= ID_FLIP;
+                        if (((take | flip) >> type) & 1u) {
+                            if (fold) q.hit(t, id0, 0u, (id0 & ID_LIT) != 0);
+                            else L.push(t, id0, 0u);
+                        }
+                    }
+                }
+                break;
+            }
             case OP_MARK: L.mark(); break;
             case OP_CSG: csg_merge(L, arg); break;
             case OP_SKIP_IF_EMPTY: {

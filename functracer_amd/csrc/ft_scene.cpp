@@ -252,6 +252,18 @@ struct Flattener {
         out.program[m.prog_at + 1] = (uint32_t)(out.program.size() - (m.prog_at + 2));
     }
 
+    // A primitive (not a mesh) under any chain of single-child scene functions: one leaf with at most a few hits.
+    bool bare_primitive(int32_t id) const {
+        for (;;) {
+            const GraphNode& n = g.nodes[id];
+            switch (n.kind) {
+                case GraphNode::Prim: return true;
+                case GraphNode::Transform: case GraphNode::MaterialF: case GraphNode::HueShift: case GraphNode::IgnoreLight: case GraphNode::Texture: id = n.children[0]; break;
+                default: return false;
+            }
+        }
+    }
+
     void walk(int32_t id, const WalkCtx& c, bool in_csg) {
         if (status != FT_OK) return;
         const GraphNode& n = g.nodes[id];
@@ -322,6 +334,9 @@ struct Flattener {
                 ++csg_depth; if (csg_depth > max_csg_depth) max_csg_depth = csg_depth;
                 int before = cur_list;
                 ItemMark im = begin_item(in_csg);
+                const bool pair = bare_primitive(n.children[0]) && bare_primitive(n.children[1]);
+                const size_t pair_at = out.program.size(), first_leaf = out.leaves.size();
+                if (pair) { out.program.push_back(0); out.program.push_back(0); out.program.push_back(0); }
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
                 walk(n.children[0], c, true);
                 const bool a_gates = n.op == FT_CSG_SUBTRACT || n.op == FT_CSG_INTERSECT;   // no A hit => empty result
@@ -333,6 +348,13 @@ struct Flattener {
                 if (a_gates) out.program[skip_at] = ftd::make_op(ftd::OP_SKIP_IF_EMPTY, (uint32_t)(out.program.size() - skip_at - 1));
                 --csg_depth;
                 if (!in_csg) { out.program.push_back(ftd::make_op(ftd::OP_FOLD_LIST, 0)); cur_list = before; }
+                if (pair && status == FT_OK && out.leaves.size() == first_leaf + 2) {
+                    out.program[pair_at] = ftd::make_op(ftd::OP_CSG_PAIR, (uint32_t)(out.program.size() - (pair_at + 3)));
+                    out.program[pair_at + 1] = (uint32_t)first_leaf;
+                    out.program[pair_at + 2] = (uint32_t)(first_leaf + 1) | ((uint32_t)n.op << 24) | (in_csg ? 0u : 1u << 26);
+                } else if (pair) {
+                    out.program.erase(out.program.begin() + (long)pair_at, out.program.begin() + (long)pair_at + 3);
+                }
                 end_item(im);
                 break;
             }
