@@ -27,8 +27,13 @@ struct DevScene {
     const double* culls;           // 24 doubles per ftd::CullRecord
     const uint32_t* tri_orig;      // 1 per triangle
     const uint8_t* tex_pixels;     // Rgb24 rows of the image textures (ftd::Texture::pixel_base indexes into it)
+    const float* cull_items;       // 8 floats per top-level item (centre, radius, row mask): wave-level pre-test of the item culls
+    const uint32_t* item_pc;       // n_items + 1 program counters: where each top-level item starts (last: the OP_END word)
+    const double* cull_rows;       // 3 per distinct parallel-sensitive direction
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
-    int32_t shadow_rays_per_hit, pad;   // sum over lights of the shadow rays the reference casts per hit
+    int32_t shadow_rays_per_hit;   // sum over lights of the shadow rays the reference casts per hit
+    int32_t n_items, n_cull_rows;  // n_cull_rows < 0: pre-test disabled
+    int32_t pad;   // sum over lights of the shadow rays the reference casts per hit
 };
 
 // Ray wavefront buffer, struct-of-arrays so a wave's 64 records are 512 contiguous bytes per field.

@@ -81,7 +81,10 @@ struct Scene {
     cdp culls;        // 24 doubles per ftd::CullRecord
     cup tri_orig;     // 1 per triangle
     const uint8_t* tex_pixels;   // per-lane byte gathers: ordinary global loads
-    int32_t n_leaves, n_lights, csg_cap, stack_cap;
+    const float* cull_items;     // lane k reads record k: ordinary global loads
+    cdp cull_rows;
+    cup item_pc;
+    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows;
 };
 static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
 template <class DS> FT_DEV Scene scene_view(const DS& g) {
@@ -92,7 +95,7 @@ template <class DS> FT_DEV Scene scene_view(const DS& g) {
     s.program = to_const_as(g.program); s.meshes = to_const_as(reinterpret_cast<const int32_t*>(g.meshes));
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig);
-    s.tex_pixels = g.tex_pixels;
+    s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
     s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
     return s;
 }
@@ -592,6 +595,85 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t bvh_root, const Ray& r, Quer
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-level pre-test of the item culls.  OP_CULL tests one item against the 64 rays of the wave, 64 lanes x ~40
+// FP64 instructions per item; scenes with tens of items spend most of a coherent batch there.  Here the roles are
+// swapped once per query: the rays of the wave are bounded by a cone (apex = origin of the first live lane, padded by
+// the largest origin distance; axis = that lane's direction; half-angle = largest deviation) and lane k tests ITEM k's
+// bounding sphere against that cone, so up to 64 items cost one pass of ~25 FP32 instructions.  Conservative by
+// construction: a sphere is dropped only when it lies wholly beyond the tangent plane of the cone nearest to it, all
+// float roundings are covered by explicit slack, and items with a parallel-sensitive face direction (Plane.fs:13-16)
+// that some ray of the wave is nearly parallel to are always kept.  Survivors still run the exact per-ray test of OP_CULL.
+FT_DEV float row16_reduce_min(float v) {
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));    // quad_perm [1,0,3,2]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));    // quad_perm [2,3,0,1]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));   // row_half_mirror
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));   // row_mirror
+    return v;
+}
+FT_DEV float wave_min(float v) {                                    // all 64 lanes must be executing
+    v = row16_reduce_min(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(a, b), fminf(c, d));
+}
+struct ItemMask { unsigned long long lo, hi; bool valid; };   // bit k: top-level item k may be hit by some ray of the wave (items >= 128: not covered)
+FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
+    ItemMask M{~0ull, ~0ull, false};
+    if (S.n_items < 3 || S.n_cull_rows < 0) return M;
+    const unsigned long long lm = __ballot(live);
+    if (lm == 0ull) return M;
+    float dx = (float)r.dx, dy = (float)r.dy, dz = (float)r.dz;
+    const float l2 = dx * dx + dy * dy + dz * dz;
+    if (__any(live && !(l2 > 1e-30f && l2 < 1e30f))) return M;      // zero / huge / NaN directions: no bound
+    const float inv = __builtin_amdgcn_rsqf(l2);
+    dx *= inv; dy *= inv; dz *= inv;
+    const float ox = (float)r.ox, oy = (float)r.oy, oz = (float)r.oz;
+    const int first = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)lm) - 1);
+    const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dx), first)), ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dy), first)),
+                az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dz), first));
+    const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox), first)), cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy), first)),
+                cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oz), first));
+    const float ex = ox - cx, ey = oy - cy, ez = oz - cz;
+    const float cos_dev = ax * dx + ay * dy + az * dz;
+    const float spread2 = ex * ex + ey * ey + ez * ez;
+    const float cos_t = wave_min(live ? cos_dev : 1.0f) - 1e-5f;    // cos of the half-angle, made smaller (cone wider)
+    const float rho2 = -wave_min(live ? -spread2 : 0.0f);
+    if (!(cos_t > 0.3f) || !(rho2 < 1e30f)) return M;               // a wide bundle bounds nothing
+    const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f;   // sine of the widened half-angle, rounded up
+    const float rho = sqrtf(rho2) * 1.0001f;
+    const float origin_mag = fabsf(cx) + fabsf(cy) + fabsf(cz);
+    // rays of the wave nearly parallel to a face direction: items using that direction are kept (exact FP64 test as in OP_CULL)
+    uint32_t par_rows = 0;
+    for (int k = 0; k < S.n_cull_rows; ++k) {
+        cdp Rw = S.cull_rows + 3u * (uint32_t)k;
+        if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
+    }
+    const int n_pass = S.n_items > 64 ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int item = pass * 64 + (int)lane_id();
+        bool keep = true;
+        if (item < S.n_items) {
+            const float* I = S.cull_items + 8 * item;
+            const float vx = I[0] - cx, vy = I[1] - cy, vz = I[2] - cz;
+            const uint32_t rows = __float_as_uint(I[4]);
+            const float slack = 1e-5f * (1.0f + origin_mag + fabsf(I[0]) + fabsf(I[1]) + fabsf(I[2]));
+            const float reach = I[3] * 1.0001f + rho + slack;       // sphere radius + origin spread + rounding slack
+            const float h = vx * ax + vy * ay + vz * az;
+            const float w = sqrtf(fmaxf(0.0f, (vx * vx + vy * vy + vz * vz) - h * h));
+            // lower bound of the distance from the centre to the cone: beyond its nearest tangent plane in front of the apex;
+            // behind the apex the cone also lies within the half-space (x - apex).axis >= 0
+            const float beyond = h > 0.0f ? w * cos_t - h * sin_t : fmaxf(w * cos_t, -h);
+            keep = !(beyond > reach) || (rows & par_rows) != 0u;
+        }
+        const unsigned long long km = __ballot(keep && item < S.n_items);
+        if (pass == 0) M.lo = km; else M.hi = km;
+    }
+    if (n_pass == 1) M.hi = 0ull;
+    M.valid = true;
+    return M;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
 // MESH = false compiles the triangle / BSP / BVH code out: scenes without meshes then run kernels with
 // markedly fewer registers (k_closest 123 -> 92 VGPRs, 4 -> 5 waves per SIMD).
@@ -600,7 +682,21 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
     HitList L;
     L.init(lds, S.csg_cap);
     int32_t* stack = reinterpret_cast<int32_t*>(lds + 4 * S.csg_cap * kBlock) + threadIdx.x;
+    // Coherent waves visit only the top-level items their ray bundle can reach (ascending, so ties between items still
+    // go to the earlier one); everything else walks the whole program, every item behind its own OP_CULL.
+    ItemMask IM{~0ull, ~0ull, false};
+    if (coherent) IM = bundle_cull(S, r, ANY ? (q.active && !q.blocked) : q.active);
+    uint32_t item_end = 0xFFFFFFFFu;
     for (uint32_t pc = 0;; ++pc) {
+        if (IM.valid && (item_end == 0xFFFFFFFFu || pc >= item_end)) {
+            int k;
+            if (IM.lo) { k = (int)__builtin_ctzll(IM.lo); IM.lo &= IM.lo - 1ull; }
+            else if (IM.hi) { k = 64 + (int)__builtin_ctzll(IM.hi); IM.hi &= IM.hi - 1ull; }
+            else if (S.n_items > 128) { k = 128; IM.valid = false; }       // the tail beyond the mask runs linearly
+            else break;
+            pc = S.item_pc[k];
+            item_end = IM.valid ? S.item_pc[k + 1] : 0xFFFFFFFFu;
+        }
         const uint32_t ins = S.program[pc];                        // wave-uniform: scalar load
         const uint32_t op = ins & 0xFFu, arg = ins >> 8;
         if (op == OP_END) break;

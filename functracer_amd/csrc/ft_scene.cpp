@@ -212,9 +212,14 @@ struct Flattener {
             default: return false;                                  // LK_PLANE: unbounded
         }
     }
+    void unbounded_item(size_t prog_at) {
+        out.item_pc.push_back((uint32_t)prog_at);
+        const float rec[8] = {0.f, 0.f, 0.f, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0.f, 0.f};
+        out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
+    }
     void end_item(const ItemMark& m) {
         if (!m.open) return;
-        auto drop = [&]() { out.program.erase(out.program.begin() + (long)m.prog_at, out.program.begin() + (long)m.prog_at + 2); };
+        auto drop = [&]() { out.program.erase(out.program.begin() + (long)m.prog_at, out.program.begin() + (long)m.prog_at + 2); if (out.program.size() > m.prog_at) unbounded_item(m.prog_at); };
         if (status != FT_OK || out.leaves.size() == m.leaf_at) { drop(); return; }
         const double inf = std::numeric_limits<double>::infinity();
         double blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
@@ -248,6 +253,20 @@ struct Flattener {
         R.n_rows = (double)rows.size();
         for (size_t k = 0; k < rows.size(); ++k) for (int a = 0; a < 3; ++a) R.rows[k][a] = rows[k][a];
         out.culls.push_back(R);
+        {   // compact copy for the wave-level pre-test (k_closest / k_shade, bundle_cull)
+            uint32_t mask = 0;
+            for (auto& v : rows) {
+                size_t k = 0;
+                for (; k < out.cull_rows.size() / 3; ++k) if (out.cull_rows[3 * k] == v[0] && out.cull_rows[3 * k + 1] == v[1] && out.cull_rows[3 * k + 2] == v[2]) break;
+                if (k == out.cull_rows.size() / 3) { if (k >= 32) { out.cull_bundle = false; break; } out.cull_rows.insert(out.cull_rows.end(), v.begin(), v.end()); }
+                mask |= 1u << k;
+            }
+            float rf = (float)r; while ((double)rf < r) rf = std::nextafter(rf, std::numeric_limits<float>::infinity());
+            float bits; std::memcpy(&bits, &mask, 4);
+            const float rec[8] = {(float)R.centre[0], (float)R.centre[1], (float)R.centre[2], rf, bits, 0.f, 0.f, 0.f};
+            out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
+            out.item_pc.push_back((uint32_t)m.prog_at);
+        }
         out.program[m.prog_at] = ftd::make_op(ftd::OP_CULL, (uint32_t)out.culls.size() - 1);
         out.program[m.prog_at + 1] = (uint32_t)(out.program.size() - (m.prog_at + 2));
     }
@@ -371,6 +390,7 @@ int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
     WalkCtx c;
     f.walk(root, c, false);
     if (f.status != FT_OK) return f.status;
+    out.item_pc.push_back((uint32_t)out.program.size());
     out.program.push_back(ftd::make_op(ftd::OP_END, 0));
     out.lights = lights;
     out.csg_capacity = f.max_list;

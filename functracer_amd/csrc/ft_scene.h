@@ -41,6 +41,10 @@ struct FlatScene {
     std::vector<double> tris;         // 9 per triangle: v0, e1, e2
     std::vector<uint32_t> tri_orig;   // 1 per triangle (see ft_flat.h)
     std::vector<ftd::CullRecord> culls;
+    std::vector<uint32_t> item_pc;    // program counter of every top-level item, in order, + one sentinel (the OP_END word)
+    std::vector<float> cull_items;    // 8 floats per top-level item: centre, radius (rounded up; +inf = unbounded), row mask (bits), pad - the wave-level pre-test
+    std::vector<double> cull_rows;    // 3 per distinct parallel-sensitive direction of the whole scene (<= 32, else the pre-test is off)
+    bool cull_bundle = true;          // false: more than 32 distinct directions
     std::vector<double> mesh_bounds;  // 6 per mesh: model-space AABB of the source triangles (lo > hi when empty)
     int32_t csg_capacity = 0;         // per-lane hit-list entries needed (0 = scene has no CSG)
     int32_t stack_capacity = 0;       // per-lane BSP / BVH stack entries needed (0 = no trees)
