@@ -112,11 +112,22 @@ struct Ray { double ox, oy, oz, dx, dy, dz; };
 struct V3 { double x, y, z; };
 
 FT_DEV double dot3(double ax, double ay, double az, double bx, double by, double bz) { return ax * bx + ay * by + az * bz; }
-FT_DEV V3 normalise(V3 v) {                                       // CommonTypes.fs:63-67
-    double l = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-    if (l < kEps) return v;
-    double s = 1.0 / l;
-    return {s * v.x, s * v.y, s * v.z};
+// Vector.normalise (CommonTypes.fs:63-67): v unchanged when |v| < eps, else (1 / |v|) * v.  1 / |v| comes from the hardware
+// reciprocal square root refined by two Newton steps (full double precision, within an ulp or two of 1 / sqrt) in place of a
+// square root followed by a division: 15 instructions instead of 35, and shading normalises seven vectors per light.
+FT_DEV V3 normalise(V3 v) {
+    const double l2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (!(l2 >= kEps * kEps) || !(l2 < 1e300)) {                    // tiny, NaN or overflowing: the reference's own sequence
+        const double l = sqrt(l2);
+        if (l < kEps) return v;
+        const double s = 1.0 / l;
+        return {s * v.x, s * v.y, s * v.z};
+    }
+    double y = __builtin_amdgcn_rsq(l2);
+    const double h = 0.5 * l2;
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+    return {y * v.x, y * v.y, y * v.z};
 }
 FT_DEV double fs_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? b : a); }  // F# max on float = Math.Max
 FT_DEV double fs_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
@@ -1251,7 +1262,20 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(ShadeArgs) {
                 const double k2 = 2.0 * dot3(ld.x, ld.y, ld.z, nn.x, nn.y, nn.z);
                 const V3 rl = normalise(V3{ld.x - k2 * nn.x, ld.y - k2 * nn.y, ld.z - k2 * nn.z});         // Vector.reflect (CommonTypes.fs:72)
                 const V3 vd = normalise(V3{r.dx, r.dy, r.dz});
-                const double si = pow(dot3(vd.x, vd.y, vd.z, -rl.x, -rl.y, -rl.z), mat.shineyness);
+                // intensity = (view . -reflected) ** shineyness.  With shineyness <= 0 the shader is black whatever the power is, so
+                // the power is only evaluated when some lane needs it; integral exponents up to 64 (the usual case) go through
+                // square-and-multiply, everything else through pow.
+                const bool wants = active && mat.shineyness > 0.0;
+                double si = 0.0;
+                if (__any(wants)) {
+                    const double base = dot3(vd.x, vd.y, vd.z, -rl.x, -rl.y, -rl.z);
+                    const bool small_int = mat.shineyness <= 64.0 && mat.shineyness == floor(mat.shineyness);
+                    if (__all(!wants || small_int)) {
+                        const uint32_t e = wants ? (uint32_t)mat.shineyness : 0u;
+                        double b = base; si = 1.0;
+                        for (uint32_t bit = 0; __any((e >> bit) != 0u); ++bit) { if ((e >> bit) & 1u) si *= b; b *= b; }
+                    } else si = pow(base, mat.shineyness);
+                }
                 if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
             }
             // reflectionShader is carried by the path weight (below)
