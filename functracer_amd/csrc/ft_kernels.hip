@@ -684,6 +684,37 @@ FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     return M;
 }
 
+// Exact skip test of one top-level item for this lane's ray (see OP_CULL).
+FT_DEV bool item_missed(const Scene& S, uint32_t item, const Ray& r) {
+    cdp C = S.culls + 24ull * item;
+    const double ocx = r.ox - C[0], ocy = r.oy - C[1], ocz = r.oz - C[2];
+    const double dd = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz), b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz), cc = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
+    // (1) the squared distance from the centre to the ray's LINE exceeds the inflated radius: no hit at any t;
+    // (2) the origin is outside the sphere and moving away: every hit of the item has t < 0, which neither
+    //     closest (Scene.fs:115) nor lightIsBocked (Scene.fs:121) ever uses (CSG state inside the item is moot).
+    // (A distance test against the light / the closest hit so far was measured: its two square roots per item cost
+    //  more than the extra skips return.)
+    bool miss = (cc * dd - b * b) > (C[3] * dd + 1e-12 * (cc * dd)) && dd > 0.0;
+    if (cc > C[3] && b > 0.0) miss = true;
+    const int n_rows = (int)C[4];
+    for (int k = 0; k < n_rows; ++k)                               // near-parallel to a plane-derived face: Plane.fs:13-16 may hit at the origin
+        if (fabs(dot3(C[5 + 3 * k], C[6 + 3 * k], C[7 + 3 * k], r.dx, r.dy, r.dz)) < 2.0 * kEps) miss = false;
+    return miss;
+}
+// The same test for every item up front (incoherent waves): the loads of consecutive records do not depend on each other,
+// unlike the walk through the program from one OP_CULL to the next, and the wave then visits only what some lane needs.
+FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
+    ItemMask M{0ull, 0ull, false};
+    const int n = S.n_items < 128 ? S.n_items : 128;
+    if (S.n_items < 3) return ItemMask{~0ull, ~0ull, false};
+    for (int k = 0; k < n; ++k) {
+        const bool need = live && !item_missed(S, (uint32_t)k, r);
+        if (__any(need)) { if (k < 64) M.lo |= 1ull << k; else M.hi |= 1ull << (k - 64); }
+    }
+    M.valid = true;
+    return M;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
 // MESH = false compiles the triangle / BSP / BVH code out: scenes without meshes then run kernels with
@@ -696,7 +727,10 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
     // Coherent waves visit only the top-level items their ray bundle can reach (ascending, so ties between items still
     // go to the earlier one); everything else walks the whole program, every item behind its own OP_CULL.
     ItemMask IM{~0ull, ~0ull, false};
-    if (coherent) IM = bundle_cull(S, r, ANY ? (q.active && !q.blocked) : q.active);
+    const bool live = ANY ? (q.active && !q.blocked) : q.active;
+    if (coherent) IM = bundle_cull(S, r, live);
+    const bool exact_mask = !IM.valid;                             // the bundle bounded nothing (or was not tried): per-ray tests up front
+    if (exact_mask) IM = exact_cull(S, r, live);
     uint32_t item_end = 0xFFFFFFFFu;
     for (uint32_t pc = 0;; ++pc) {
         if (IM.valid && (item_end == 0xFFFFFFFFu || pc >= item_end)) {
@@ -705,8 +739,10 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
             else if (IM.hi) { k = 64 + (int)__builtin_ctzll(IM.hi); IM.hi &= IM.hi - 1ull; }
             else if (S.n_items > 128) { k = 128; IM.valid = false; }       // the tail beyond the mask runs linearly
             else break;
-            pc = S.item_pc[k];
-            item_end = IM.valid ? S.item_pc[k + 1] : 0xFFFFFFFFu;
+            const uint32_t at = S.item_pc[k];
+            pc = at & 0x7FFFFFFFu;
+            if (exact_mask && IM.valid && (at >> 31)) pc += 2;     // its OP_CULL was already evaluated for every lane
+            item_end = IM.valid ? (S.item_pc[k + 1] & 0x7FFFFFFFu) : 0xFFFFFFFFu;
         }
         const uint32_t ins = S.program[pc];                        // wave-uniform: scalar load
         const uint32_t op = ins & 0xFFu, arg = ins >> 8;
@@ -745,19 +781,7 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
             }
             case OP_CULL: {
                 // Exact skip of a whole item: taken only when NO lane of the wave can produce a hit on it.
-                cdp C = S.culls + 24ull * arg;
-                const double ocx = r.ox - C[0], ocy = r.oy - C[1], ocz = r.oz - C[2];
-                const double dd = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz), b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz), cc = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
-                // (1) the squared distance from the centre to the ray's LINE exceeds the inflated radius: no hit at any t;
-                // (2) the origin is outside the sphere and moving away: every hit of the item has t < 0, which neither
-                //     closest (Scene.fs:115) nor lightIsBocked (Scene.fs:121) ever uses (CSG state inside the item is moot).
-                // (A distance test against the light / the closest hit so far was measured: its two square roots per item cost
-                //  more than the extra skips return.)
-                bool miss = (cc * dd - b * b) > (C[3] * dd + 1e-12 * (cc * dd)) && dd > 0.0;
-                if (cc > C[3] && b > 0.0) miss = true;
-                const int n_rows = (int)C[4];
-                for (int k = 0; k < n_rows; ++k)                   // near-parallel to a plane-derived face: Plane.fs:13-16 may hit at the origin
-                    if (fabs(dot3(C[5 + 3 * k], C[6 + 3 * k], C[7 + 3 * k], r.dx, r.dy, r.dz)) < 2.0 * kEps) miss = false;
+                const bool miss = item_missed(S, arg, r);
                 bool need = q.active && !miss;
                 if (ANY) need = need && !q.blocked;
                 ++pc;
@@ -1058,8 +1082,11 @@ struct ClosestArgs {
     uint32_t* hit_list; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc; int32_t bounce;
 };
 
+#ifndef FT_CLOSEST_BLOCKS
+#define FT_CLOSEST_BLOCKS 4
+#endif
 template <bool MESH>
-__global__ __launch_bounds__(kBlock, 4) void k_closest(ClosestArgs) {
+__global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST ClosestArgs* K = kernel_args<ClosestArgs>();
     const Scene S = scene_view(K->S);
@@ -1150,7 +1177,10 @@ struct ShadeArgs {
 };
 
 template <bool FANCY, bool SOFT, bool MESH>
-__global__ __launch_bounds__(kBlock, FANCY ? 2 : 3) void k_shade(ShadeArgs) {
+#ifndef FT_SHADE_BLOCKS
+#define FT_SHADE_BLOCKS 4
+#endif
+__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(ShadeArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST ShadeArgs* K = kernel_args<ShadeArgs>();
     const Scene S = scene_view(K->S);

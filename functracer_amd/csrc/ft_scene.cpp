@@ -214,6 +214,9 @@ struct Flattener {
     }
     void unbounded_item(size_t prog_at) {
         out.item_pc.push_back((uint32_t)prog_at);
+        ftd::CullRecord never{};                                    // cull records are indexed by item: this one can never report a miss
+        never.radius2 = std::numeric_limits<double>::infinity();
+        out.culls.push_back(never);
         const float rec[8] = {0.f, 0.f, 0.f, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0.f, 0.f};
         out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
     }
@@ -265,7 +268,7 @@ struct Flattener {
             float bits; std::memcpy(&bits, &mask, 4);
             const float rec[8] = {(float)R.centre[0], (float)R.centre[1], (float)R.centre[2], rf, bits, 0.f, 0.f, 0.f};
             out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
-            out.item_pc.push_back((uint32_t)m.prog_at);
+            out.item_pc.push_back((uint32_t)m.prog_at | 0x80000000u);   // top bit: the item starts with its OP_CULL pair
         }
         out.program[m.prog_at] = ftd::make_op(ftd::OP_CULL, (uint32_t)out.culls.size() - 1);
         out.program[m.prog_at + 1] = (uint32_t)(out.program.size() - (m.prog_at + 2));
