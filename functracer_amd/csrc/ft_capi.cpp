@@ -38,6 +38,7 @@ struct ft_context {
     bool committed = false;
 
     int64_t chunk_samples = 8ll << 20;
+    int64_t tail_rays = 65536;       // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM
     DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc;
@@ -211,6 +212,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!c || !key) return FT_ERR_INVALID;
     if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; for (ft_context* p : c->peers) p->chunk_samples = value; return FT_OK; }
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
+    if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
     return FT_ERR_INVALID;
@@ -543,6 +545,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
     ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds, variant), lds, variant};
     ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds, variant), lds, variant};
+    ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_tail(lds, variant), lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
     const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
@@ -575,9 +578,13 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
                                (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
                                1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h)};
         for (int b = 0; b <= last_bounce; ++b) {
-            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, cc, rcount); });
+            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, (uint32_t)c->tail_rays, cc, rcount); });
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
             n_launches += 2;
+        }
+        if (last_bounce >= 1 && c->tail_rays > 0) {
+            timed(2, [&] { ftk::launch_tail(Lt, c->dev_scene, gen, rb[0], rb[1], c->d_acc.as<double>(), n_samples, max_depth, (uint32_t)c->tail_rays, cc, rcount); });
+            ++n_launches;
         }
         const uint32_t* out_index = !whole ? nullptr : (corner ? c->d_out_index.as<uint32_t>() : c->d_pixels.as<uint32_t>()) + job.out_base;
         double* out_ptr = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
@@ -606,12 +613,17 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         stats->hits_primary = hrc.hits_primary; stats->csg_overflow = hrc.csg_overflow;
         stats->kernel_ms = ms; stats->trace_kernel_ms = c->k_ms[1] + c->k_ms[2];
         {   // bytes the pipeline has to move by construction (ft_device.h); P primary rays, R reflection rays, H hits, H0 primary hits
-            const uint64_t P = stats->rays_primary, R = hrc.rays_reflect, H = hrc.hits_total, H0 = hrc.hits_primary, HL = H - std::min(H, H0);
-            stats->hits_total = H;
+            // rays and hits that k_tail handled never became records: Ti rays were handed to it (written once, read once), Tr spawned and Th shaded inside it
+            const uint64_t P = stats->rays_primary, Ti = hrc.tail_in, Tr = hrc.tail_rays, Th = hrc.tail_hits, RR = hrc.rays_reflect, HH = hrc.hits_total;
+            const uint64_t R = RR - std::min(RR, Ti + Tr), Rw = RR - std::min(RR, Tr);
+            const uint64_t H = HH - std::min(HH, Th), H0 = hrc.hits_primary, HL = H - std::min(H, H0);
+            stats->hits_total = hrc.hits_total;
+            stats->rays_tail = Ti + Tr;
             stats->algorithmic_bytes_closest = P * (ftk::kPixelIdBytes + ftk::kTouchedBytes) + R * 48 + H * (ftk::kHitRecBytes + ftk::kListBytes);
             stats->algorithmic_bytes_shade = H * (ftk::kHitRecBytes + ftk::kListBytes) + H0 * (2 * ftk::kPixelIdBytes + ftk::kAccBytes) +
-                                             HL * (48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + R * ftk::kRayRecBytes;
+                                             HL * (48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + Rw * ftk::kRayRecBytes;
             stats->algorithmic_bytes = stats->algorithmic_bytes_closest + stats->algorithmic_bytes_shade +
+                                       Ti * ftk::kRayRecBytes + Th * 2 * ftk::kAccBytes +                       // + k_tail
                                        P * ftk::kTouchedBytes + H0 * ftk::kAccBytes + 24ull * (uint64_t)n_pix_total;   // + k_blend
         }
         stats->n_launches = n_launches; stats->n_chunks = n_chunks;

@@ -60,6 +60,7 @@ struct RenderCounters {
     unsigned long long rays_shadow, rays_reflect, hits_primary, csg_overflow;
     double ref_equiv;
     unsigned long long hits_total;      // hits shaded over all bounces
+    unsigned long long tail_in, tail_rays, tail_hits;   // k_tail: rays handed over, reflection rays it spawned, hits it shaded
 };
 
 struct Camera {                    // ImagePlane (Image.fs:55-63), computed on the host
@@ -91,9 +92,14 @@ struct Primary {
 // K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.  Bounce 0 also records, one
 // byte per sample, whether the primary ray hit anything (`touched`): untouched samples are Colour.Zero and their accumulator is
 // neither cleared nor read.
-void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce,
+void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, uint32_t tail_threshold,
                     ChunkCounters* cc, RenderCounters* rc);
 // K3: shading + shadow rays + accumulation for the compacted hits of bounce k; emits bounce k+1 rays.
+// Tail of the bounce loop (k_tail): once a bounce has fewer than `threshold` rays the per-bounce stages stand down and this one
+// launch follows every remaining path to its end inside registers.
+void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
+                 int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc);
+int occupancy_blocks_tail(size_t lds_bytes, int variant);
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
                   double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).

@@ -1079,7 +1079,7 @@ FT_DEV Ray primary_ray(PrimaryArg g, uint32_t i) { return primary_ray_from(g, i,
 
 struct ClosestArgs {
     DevScene S; Primary gen; RayBuf rays; HitBuf hits;
-    uint32_t* hit_list; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc; int32_t bounce;
+    uint32_t* hit_list; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc; int32_t bounce; uint32_t tail_threshold;
 };
 
 #ifndef FT_CLOSEST_BLOCKS
@@ -1094,6 +1094,7 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
     ChunkCounters* cc = K->cc;
     const uint32_t n_pix = K->gen.n_pix;
     const uint32_t n = bounce == 0 ? n_pix * (uint32_t)K->gen.spp : cc->n_rays[bounce];
+    if (bounce > 0 && n < K->tail_threshold) return;               // few rays left: k_tail follows them to the end (nothing is spawned after this bounce)
     const uint32_t B = batch_lanes_for(n);
     const uint32_t n_batches = (n + B - 1) / B;
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
@@ -1170,6 +1171,125 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
 // Two passes over the lights keep the live state across the shadow traces small (p, n and a few words instead
 // of the whole fragment state): pass 1 only decides visibility (one byte per light: occluded sample count),
 // pass 2 reloads the ray and the material and evaluates the shaders.
+// getLightsOnPoint (Shading.fs:109-117), visibility half: one shadow query per light (per sample of a soft light) from the
+// surface point; byte l of (vis_lo, vis_hi) = number of occluded samples of light l.
+template <bool SOFT, bool MESH, class SeedFn>
+FT_DEV void light_visibility(const Scene& S, const Surface& sf, bool lit, unsigned long long sample, SeedFn&& seed_of, int bounce, bool coherent, uint32_t* lds,
+                             unsigned long long& vis_lo, unsigned long long& vis_hi, unsigned long long& n_shadow_wave, unsigned long long& n_ovf_wave) {
+    const int n_lights = S.n_lights;
+    vis_lo = 0ull; vis_hi = 0ull;
+    for (int l = 0; l < n_lights; ++l) {                       // wave-uniform; getLightsOnPoint (Shading.fs:109-117)
+        cdp lp = S.lights + 12ull * (uint32_t)l;               // scalar loads
+        const uint32_t kind = reinterpret_cast<cup>(lp + 10)[0];
+        const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
+        unsigned long long occluded = 0ull;
+        bool overflow = false;
+        if (SOFT && kind == LT_SOFT) {                         // softShadowLightIntensity (Shading.fs:24-31)
+            const int samples = reinterpret_cast<cip>(lp + 10)[1];
+            const JitterFrame frame(V3{-lp[0], -lp[1], -lp[2]}, lp[11]);
+            Rng rng = make_rng(seed_of(), sample, (uint32_t)bounce, (uint32_t)l, 1u);
+            for (int k = 0; k < samples; ++k) {                // wave-uniform count; each lane draws its own direction
+                const V3 dj = frame.jittered(rng);
+                Query<true> qs;
+                qs.active = lit; qs.blocked = false; qs.best_t = 0; qs.id0 = 0; qs.id1 = 0; qs.max_dist = 1.7976931348623157e308;
+                bool ovf = false;
+                if (__any(lit)) trace<true, MESH>(S, Ray{sox, soy, soz, dj.x, dj.y, dj.z}, qs, lds, ovf, false);
+                if (qs.blocked) ++occluded;
+                overflow = overflow || ovf;
+                n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
+            }
+        } else {
+            Query<true> q;
+            q.active = lit; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0;
+            Ray sr;
+            if (kind == LT_POINT) {                            // shadowLightIntensity (Shading.fs:33-42)
+                const double ddx = lp[0] - sox, ddy = lp[1] - soy, ddz = lp[2] - soz;
+                q.max_dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+                const V3 dn = normalise(V3{ddx, ddy, ddz});
+                sr = {sox, soy, soz, dn.x, dn.y, dn.z};
+            } else {
+                sr = {sox, soy, soz, -lp[0], -lp[1], -lp[2]};
+                q.max_dist = 1.7976931348623157e308;           // System.Double.MaxValue
+            }
+            if (__any(lit)) trace<true, MESH>(S, sr, q, lds, overflow, coherent);
+            n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
+            occluded = q.blocked ? 1ull : 0ull;
+        }
+        n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && lit));
+        if (l < 8) vis_lo |= occluded << (8 * l); else vis_hi |= occluded << (8 * (l - 8));
+    }
+}
+
+// The shaders of Shading.fs:50-107 over all lights for one hit: sum of specular + diffuse fragments (the reflection shader
+// travels with the path weight).
+template <bool FANCY, bool SOFT>
+FT_DEV void shade_lights(const Scene& S, const Surface& sf, const MaterialV& mat, const Ray& r, bool active, bool lit,
+                         unsigned long long vis_lo, unsigned long long vis_hi, double& cr, double& cg, double& cb) {
+    const int n_lights = S.n_lights;
+    cr = 0.0; cg = 0.0; cb = 0.0;                                  // sum over fragments (Seq.sumBy shader, Shading.fs:139)
+    for (int l = 0; l < n_lights; ++l) {
+        if (active && !lit) { cr += mat.colour[0]; cg += mat.colour[1]; cb += mat.colour[2]; }   // shadeIfRequired (Shading.fs:100-104)
+        if (!lit) continue;
+        cdp lp = S.lights + 12ull * (uint32_t)l;
+        const uint32_t kind = reinterpret_cast<cup>(lp + 10)[0];
+        const double occluded = (double)((l < 8 ? vis_lo >> (8 * l) : vis_hi >> (8 * (l - 8))) & 0xFFull);
+        double intensity; V3 ld;
+        if (kind == LT_POINT) {                                // Light.attenuate (Light.fs:16-17), lightDirection (Shading.fs:44-48)
+            const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
+            const double ddx = lp[0] - sox, ddy = lp[1] - soy, ddz = lp[2] - soz;
+            const double dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+            intensity = occluded != 0.0 ? 0.0 : 1.0 / (lp[3] + dist * (lp[4] + dist * lp[5]));
+            ld = normalise(V3{sf.p.x - lp[0], sf.p.y - lp[1], sf.p.z - lp[2]});
+        } else {
+            if (SOFT && kind == LT_SOFT) { const double samples = (double)reinterpret_cast<cip>(lp + 10)[1]; intensity = (samples - occluded) / samples; }
+            else intensity = occluded != 0.0 ? 0.0 : 1.0;
+            ld = {lp[0], lp[1], lp[2]};
+        }
+        const double lcr = intensity * lp[6], lcg = intensity * lp[7], lcb = intensity * lp[8];   // scaleColour (Image.fs:25-26)
+        double fr = 0.0, fg = 0.0, fb = 0.0;
+        {                                                      // specularShader (Shading.fs:78-87)
+            const V3 nn = normalise(sf.n);
+            const double k2 = 2.0 * dot3(ld.x, ld.y, ld.z, nn.x, nn.y, nn.z);
+            const V3 rl = normalise(V3{ld.x - k2 * nn.x, ld.y - k2 * nn.y, ld.z - k2 * nn.z});         // Vector.reflect (CommonTypes.fs:72)
+            const V3 vd = normalise(V3{r.dx, r.dy, r.dz});
+            // intensity = (view . -reflected) ** shineyness.  With shineyness <= 0 the shader is black whatever the power is, so
+            // the power is only evaluated when some lane needs it; integral exponents up to 64 (the usual case) go through
+            // square-and-multiply, everything else through pow.
+            const bool wants = active && mat.shineyness > 0.0;
+            double si = 0.0;
+            if (__any(wants)) {                                   // each lane takes its own route: a ray's result must not depend on its wave
+                const double base = dot3(vd.x, vd.y, vd.z, -rl.x, -rl.y, -rl.z);
+                const bool small_int = mat.shineyness <= 64.0 && mat.shineyness == floor(mat.shineyness);
+                if (__any(wants && small_int)) {
+                    const uint32_t e = (wants && small_int) ? (uint32_t)mat.shineyness : 0u;
+                    double b = base, pw = 1.0;
+                    for (uint32_t bit = 0; __any((e >> bit) != 0u); ++bit) { if ((e >> bit) & 1u) pw *= b; b *= b; }
+                    if (wants && small_int) si = pw;
+                }
+                if (__any(wants && !small_int)) { const double pw = pow(base, mat.shineyness); if (wants && !small_int) si = pw; }
+            }
+            if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
+        }
+        // reflectionShader is carried by the path weight (below)
+        if (!FANCY || mat.roughness == 0.0) {                  // diffuseShader -> lambertianDiffuse (Shading.fs:65-76)
+            const double di = dot3(-ld.x, -ld.y, -ld.z, sf.n.x, sf.n.y, sf.n.z);
+            fr = fr + di * (mat.colour[0] * lcr); fg = fg + di * (mat.colour[1] * lcg); fb = fb + di * (mat.colour[2] * lcb);
+        } else {                                               // roughDiffuse: Oren-Nayar (Shading.fs:50-63); the light colour is not used (sic)
+            const double rough = mat.roughness * mat.roughness;
+            const V3 nn = normalise(sf.n), nv = normalise(V3{-r.dx, -r.dy, -r.dz}), nl = normalise(V3{-ld.x, -ld.y, -ld.z});
+            const double ray_angle = acos(dot3(nn.x, nn.y, nn.z, nv.x, nv.y, nv.z)), light_angle = acos(dot3(nn.x, nn.y, nn.z, nl.x, nl.y, nl.z));
+            const double alpha = fs_max(ray_angle, light_angle), beta = fs_min(ray_angle, light_angle);
+            const double A = 1.0 - 0.5 * rough / (rough + 0.33), B = 0.45 * rough / (rough + 0.09);
+            const double kl = dot3(-ld.x, -ld.y, -ld.z, nn.x, nn.y, nn.z), kv = dot3(-r.dx, -r.dy, -r.dz, nn.x, nn.y, nn.z);
+            const V3 tl = normalise(V3{-ld.x - kl * nn.x, -ld.y - kl * nn.y, -ld.z - kl * nn.z});   // perpendicularComponent (CommonTypes.fs:77-79)
+            const V3 tr = normalise(V3{-r.dx - kv * nn.x, -r.dy - kv * nn.y, -r.dz - kv * nn.z});
+            const double di = cos(light_angle) * (A + (B * fs_max(0.0, dot3(tl.x, tl.y, tl.z, tr.x, tr.y, tr.z)) * sin(alpha) * tan(beta)));
+            fr = fr + di * mat.colour[0]; fg = fg + di * mat.colour[1]; fb = fb + di * mat.colour[2];
+        }
+        cr += fr; cg += fg; cb += fb;
+    }
+}
+
 struct ShadeArgs {
     DevScene S; Primary gen; RayBuf rays; HitBuf hits; RayBuf next;
     const uint32_t* hit_list; double* acc; ChunkCounters* cc; RenderCounters* rc;
@@ -1214,47 +1334,8 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
             lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
             if (SOFT) sample = sample_id(&Kb->gen, slot);
         }
-        unsigned long long vis_lo = 0ull, vis_hi = 0ull;           // byte l = occluded shadow samples of light l
-        for (int l = 0; l < n_lights; ++l) {                       // wave-uniform; getLightsOnPoint (Shading.fs:109-117)
-            cdp lp = S.lights + 12ull * (uint32_t)l;               // scalar loads
-            const uint32_t kind = reinterpret_cast<cup>(lp + 10)[0];
-            const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
-            unsigned long long occluded = 0ull;
-            bool overflow = false;
-            if (SOFT && kind == LT_SOFT) {                         // softShadowLightIntensity (Shading.fs:24-31)
-                const int samples = reinterpret_cast<cip>(lp + 10)[1];
-                const JitterFrame frame(V3{-lp[0], -lp[1], -lp[2]}, lp[11]);
-                Rng rng = make_rng(fresh(K)->gen.seed, sample, (uint32_t)bounce, (uint32_t)l, 1u);
-                for (int k = 0; k < samples; ++k) {                // wave-uniform count; each lane draws its own direction
-                    const V3 dj = frame.jittered(rng);
-                    Query<true> qs;
-                    qs.active = lit; qs.blocked = false; qs.best_t = 0; qs.id0 = 0; qs.id1 = 0; qs.max_dist = 1.7976931348623157e308;
-                    bool ovf = false;
-                    if (__any(lit)) trace<true, MESH>(S, Ray{sox, soy, soz, dj.x, dj.y, dj.z}, qs, lds, ovf, false);
-                    if (qs.blocked) ++occluded;
-                    overflow = overflow || ovf;
-                    n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
-                }
-            } else {
-                Query<true> q;
-                q.active = lit; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0;
-                Ray sr;
-                if (kind == LT_POINT) {                            // shadowLightIntensity (Shading.fs:33-42)
-                    const double ddx = lp[0] - sox, ddy = lp[1] - soy, ddz = lp[2] - soz;
-                    q.max_dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
-                    const V3 dn = normalise(V3{ddx, ddy, ddz});
-                    sr = {sox, soy, soz, dn.x, dn.y, dn.z};
-                } else {
-                    sr = {sox, soy, soz, -lp[0], -lp[1], -lp[2]};
-                    q.max_dist = 1.7976931348623157e308;           // System.Double.MaxValue
-                }
-                if (__any(lit)) trace<true, MESH>(S, sr, q, lds, overflow, bounce == 0);
-                n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
-                occluded = q.blocked ? 1ull : 0ull;
-            }
-            n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && lit));
-            if (l < 8) vis_lo |= occluded << (8 * l); else vis_hi |= occluded << (8 * (l - 8));
-        }
+        unsigned long long vis_lo, vis_hi;                         // byte l = occluded shadow samples of light l
+        light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, bounce, bounce == 0, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
         // ---------------- pass 2: the shaders (Shading.fs:50-107) with everything reloaded ------------------
         Ray r{0, 0, 0, 0, 0, 0};
         double w = 0.0; uint32_t slot = 0;
@@ -1266,66 +1347,8 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
         }
         MaterialV mat = material_at(S, sf.material);               // per-lane gather (64 B records, L1/L2 resident)
         if (FANCY) { if (active && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }   // Ray.textureDiffuse (Ray.fs:57-59)
-        double cr = 0.0, cg = 0.0, cb = 0.0;                       // sum over fragments (Seq.sumBy shader, Shading.fs:139)
-        for (int l = 0; l < n_lights; ++l) {
-            if (active && !lit) { cr += mat.colour[0]; cg += mat.colour[1]; cb += mat.colour[2]; }   // shadeIfRequired (Shading.fs:100-104)
-            if (!lit) continue;
-            cdp lp = S.lights + 12ull * (uint32_t)l;
-            const uint32_t kind = reinterpret_cast<cup>(lp + 10)[0];
-            const double occluded = (double)((l < 8 ? vis_lo >> (8 * l) : vis_hi >> (8 * (l - 8))) & 0xFFull);
-            double intensity; V3 ld;
-            if (kind == LT_POINT) {                                // Light.attenuate (Light.fs:16-17), lightDirection (Shading.fs:44-48)
-                const double sox = sf.p.x + 0.0001 * sf.n.x, soy = sf.p.y + 0.0001 * sf.n.y, soz = sf.p.z + 0.0001 * sf.n.z;
-                const double ddx = lp[0] - sox, ddy = lp[1] - soy, ddz = lp[2] - soz;
-                const double dist = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
-                intensity = occluded != 0.0 ? 0.0 : 1.0 / (lp[3] + dist * (lp[4] + dist * lp[5]));
-                ld = normalise(V3{sf.p.x - lp[0], sf.p.y - lp[1], sf.p.z - lp[2]});
-            } else {
-                if (SOFT && kind == LT_SOFT) { const double samples = (double)reinterpret_cast<cip>(lp + 10)[1]; intensity = (samples - occluded) / samples; }
-                else intensity = occluded != 0.0 ? 0.0 : 1.0;
-                ld = {lp[0], lp[1], lp[2]};
-            }
-            const double lcr = intensity * lp[6], lcg = intensity * lp[7], lcb = intensity * lp[8];   // scaleColour (Image.fs:25-26)
-            double fr = 0.0, fg = 0.0, fb = 0.0;
-            {                                                      // specularShader (Shading.fs:78-87)
-                const V3 nn = normalise(sf.n);
-                const double k2 = 2.0 * dot3(ld.x, ld.y, ld.z, nn.x, nn.y, nn.z);
-                const V3 rl = normalise(V3{ld.x - k2 * nn.x, ld.y - k2 * nn.y, ld.z - k2 * nn.z});         // Vector.reflect (CommonTypes.fs:72)
-                const V3 vd = normalise(V3{r.dx, r.dy, r.dz});
-                // intensity = (view . -reflected) ** shineyness.  With shineyness <= 0 the shader is black whatever the power is, so
-                // the power is only evaluated when some lane needs it; integral exponents up to 64 (the usual case) go through
-                // square-and-multiply, everything else through pow.
-                const bool wants = active && mat.shineyness > 0.0;
-                double si = 0.0;
-                if (__any(wants)) {
-                    const double base = dot3(vd.x, vd.y, vd.z, -rl.x, -rl.y, -rl.z);
-                    const bool small_int = mat.shineyness <= 64.0 && mat.shineyness == floor(mat.shineyness);
-                    if (__all(!wants || small_int)) {
-                        const uint32_t e = wants ? (uint32_t)mat.shineyness : 0u;
-                        double b = base; si = 1.0;
-                        for (uint32_t bit = 0; __any((e >> bit) != 0u); ++bit) { if ((e >> bit) & 1u) si *= b; b *= b; }
-                    } else si = pow(base, mat.shineyness);
-                }
-                if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
-            }
-            // reflectionShader is carried by the path weight (below)
-            if (!FANCY || mat.roughness == 0.0) {                  // diffuseShader -> lambertianDiffuse (Shading.fs:65-76)
-                const double di = dot3(-ld.x, -ld.y, -ld.z, sf.n.x, sf.n.y, sf.n.z);
-                fr = fr + di * (mat.colour[0] * lcr); fg = fg + di * (mat.colour[1] * lcg); fb = fb + di * (mat.colour[2] * lcb);
-            } else {                                               // roughDiffuse: Oren-Nayar (Shading.fs:50-63); the light colour is not used (sic)
-                const double rough = mat.roughness * mat.roughness;
-                const V3 nn = normalise(sf.n), nv = normalise(V3{-r.dx, -r.dy, -r.dz}), nl = normalise(V3{-ld.x, -ld.y, -ld.z});
-                const double ray_angle = acos(dot3(nn.x, nn.y, nn.z, nv.x, nv.y, nv.z)), light_angle = acos(dot3(nn.x, nn.y, nn.z, nl.x, nl.y, nl.z));
-                const double alpha = fs_max(ray_angle, light_angle), beta = fs_min(ray_angle, light_angle);
-                const double A = 1.0 - 0.5 * rough / (rough + 0.33), B = 0.45 * rough / (rough + 0.09);
-                const double kl = dot3(-ld.x, -ld.y, -ld.z, nn.x, nn.y, nn.z), kv = dot3(-r.dx, -r.dy, -r.dz, nn.x, nn.y, nn.z);
-                const V3 tl = normalise(V3{-ld.x - kl * nn.x, -ld.y - kl * nn.y, -ld.z - kl * nn.z});   // perpendicularComponent (CommonTypes.fs:77-79)
-                const V3 tr = normalise(V3{-r.dx - kv * nn.x, -r.dy - kv * nn.y, -r.dz - kv * nn.z});
-                const double di = cos(light_angle) * (A + (B * fs_max(0.0, dot3(tl.x, tl.y, tl.z, tr.x, tr.y, tr.z)) * sin(alpha) * tan(beta)));
-                fr = fr + di * mat.colour[0]; fg = fg + di * mat.colour[1]; fb = fb + di * mat.colour[2];
-            }
-            cr += fr; cg += fg; cb += fb;
-        }
+        double cr, cg, cb;
+        shade_lights<FANCY, SOFT>(S, sf, mat, r, active, lit, vis_lo, vis_hi, cr, cg, cb);
         if (active) {                                              // one ray per sample per bounce: no write conflicts, fixed order
             double* acc = K2->acc; const uint32_t acc_stride = K2->acc_stride;
             if (bounce == 0) {                                     // first contribution of the sample: 0 + x = x, so a plain store replaces clear + add
@@ -1368,11 +1391,106 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_tail: the end of the bounce loop as one launch.  Late bounces carry few, incoherent rays; run as closest / shade stages
+// each of them costs two launches whose time is the latency of a single batch (~30-100 us: every stage boundary sends the
+// ray and hit records through HBM, across XCDs).  Once a bounce k >= 1 starts with fewer than `threshold` rays, k_closest
+// stands down (so nothing more is spawned) and this kernel takes those rays and follows every path to its end - closest hit,
+// shadow queries, shaders, reflection - with the ray in registers.  Same device functions, same arithmetic and the same
+// accumulation order per sample as the staged bounces, so frames do not depend on where the hand-over happens.
+struct TailArgs {
+    DevScene S; Primary gen; RayBuf rays[2];
+    double* acc; ChunkCounters* cc; RenderCounters* rc;
+    uint32_t acc_stride; int32_t max_depth; uint32_t threshold;
+};
+
+template <bool FANCY, bool SOFT, bool MESH>
+__global__ __launch_bounds__(kBlock, 2) void k_tail(TailArgs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const FT_CONST TailArgs* K = kernel_args<TailArgs>();
+    ChunkCounters* cc = K->cc;
+    const int max_depth = K->max_depth;
+    int k0 = 0; uint32_t n = 0;
+    for (int k = 1; k <= max_depth; ++k) { const uint32_t nk = cc->n_rays[k]; if (nk > 0u && nk < K->threshold) { k0 = k; n = nk; break; } }
+    if (k0 == 0) return;
+    const Scene S = scene_view(K->S);
+    const int n_lights = S.n_lights;
+    unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0, n_in_wave = 0;
+    double ref_wave = 0.0;
+    const uint32_t B = batch_lanes_for(n);
+    const uint32_t n_batches = (n + B - 1) / B;
+    BatchCursor cursor(&cc->work_trace[kMaxBounce + 1][0]);       // a cursor row no bounce uses
+    for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
+        const uint32_t i = bi * B + lane_id();
+        bool alive = i < n && lane_id() < B;
+        Ray r{0, 0, 0, 0, 0, 0};
+        double w = 0.0; uint32_t slot = 0;
+        if (alive) {
+            const FT_CONST RayBuf& rays = fresh(K)->rays[k0 & 1];
+            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i];
+        }
+        n_in_wave += (unsigned long long)__popcll(__ballot(alive));
+        double mult = pow((double)n_lights, (double)k0);          // copies of this ray in the F# recursion (Shading.fs:109-139)
+        for (int depth = k0; __any(alive); ++depth, mult *= (double)n_lights) {
+            // ---- closest hit (k_closest)
+            Query<false> q;
+            q.active = alive; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
+            const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
+            bool overflow;
+            trace<false, MESH>(S, ro, q, lds, overflow, false);
+            n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && alive));
+            alive = alive && q.id0 != ID_MISS;
+            const unsigned long long hit_mask = __ballot(alive);
+            if (hit_mask == 0ull) break;
+            // ---- shade (k_shade)
+            Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
+            bool lit = false;
+            unsigned long long sample = 0ull;
+            if (alive) {
+                sf = surface_at<FANCY>(S, ro, q.best_t, q.id0, q.id1);
+                lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
+                if (SOFT) sample = sample_id(&fresh(K)->gen, slot);
+            }
+            unsigned long long vis_lo, vis_hi;
+            light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, depth, false, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
+            MaterialV mat = material_at(S, sf.material);
+            if (FANCY) { if (alive && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
+            double cr, cg, cb;
+            shade_lights<FANCY, SOFT>(S, sf, mat, r, alive, lit, vis_lo, vis_hi, cr, cg, cb);
+            if (alive) {
+                const FT_CONST TailArgs* Ka = fresh(K);
+                double* acc = Ka->acc; const uint32_t acc_stride = Ka->acc_stride;
+                acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
+            }
+            const bool spawn = lit && mat.reflectance > 0.0 && depth < max_depth;          // reflectionShader (Shading.fs:89-98), see k_shade
+            const uint32_t n_hit = (uint32_t)__popcll(hit_mask), n_spawn = (uint32_t)__popcll(__ballot(spawn));
+            n_hit_wave += n_hit; n_refl_wave += n_spawn;
+            ref_wave += mult * ((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit + (double)n_lights * (double)n_spawn);
+            if (spawn) {
+                const double k2 = 2.0 * dot3(r.dx, r.dy, r.dz, sf.n.x, sf.n.y, sf.n.z);
+                r = {sf.p.x, sf.p.y, sf.p.z, r.dx - k2 * sf.n.x, r.dy - k2 * sf.n.y, r.dz - k2 * sf.n.z};
+                w = w * (mat.reflectance * (double)n_lights);
+            }
+            alive = spawn;
+        }
+    }
+    RenderCounters* mine = my_stats(fresh(K)->rc);
+    wave_add(&mine->rays_shadow, n_shadow_wave);
+    wave_add(&mine->rays_reflect, n_refl_wave);
+    wave_add(&mine->hits_total, n_hit_wave);
+    wave_add(&mine->csg_overflow, n_ovf_wave);
+    wave_add(&mine->tail_in, n_in_wave);
+    wave_add(&mine->tail_rays, n_refl_wave);
+    wave_add(&mine->tail_hits, n_hit_wave);
+    if (lane_id() == 0 && ref_wave != 0.0) mine->ref_equiv += ref_wave;
+}
+
 __global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, uint32_t n_slots) {   // one block; slot 0 receives the totals
     __shared__ RenderCounters part[kBlock];
-    RenderCounters s{0, 0, 0, 0, 0.0, 0};
+    RenderCounters s{0, 0, 0, 0, 0.0, 0, 0, 0, 0};
     for (uint32_t k = 1 + threadIdx.x; k <= n_slots; k += kBlock) {
         s.rays_shadow += slots[k].rays_shadow; s.rays_reflect += slots[k].rays_reflect; s.hits_primary += slots[k].hits_primary;
+        s.tail_in += slots[k].tail_in; s.tail_rays += slots[k].tail_rays; s.tail_hits += slots[k].tail_hits;
         s.csg_overflow += slots[k].csg_overflow; s.ref_equiv += slots[k].ref_equiv; s.hits_total += slots[k].hits_total;
     }
     part[threadIdx.x] = s;
@@ -1381,6 +1499,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, 
         RenderCounters t = slots[0];                              // debug kernels add to slot 0 directly
         for (int k = 0; k < kBlock; ++k) {
             t.rays_shadow += part[k].rays_shadow; t.rays_reflect += part[k].rays_reflect; t.hits_primary += part[k].hits_primary;
+            t.tail_in += part[k].tail_in; t.tail_rays += part[k].tail_rays; t.tail_hits += part[k].tail_hits;
             t.csg_overflow += part[k].csg_overflow; t.ref_equiv += part[k].ref_equiv; t.hits_total += part[k].hits_total;
         }
         slots[0] = t;
@@ -1475,11 +1594,25 @@ static ShadeKernel shade_variant(int v) {                          // bit 0 FANC
     }
 }
 
+typedef void (*TailKernel)(TailArgs);
+static TailKernel tail_variant(int v) {
+    switch (v & 7) {
+        case 0: return k_tail<false, false, false>;
+        case 1: return k_tail<true, false, false>;
+        case 2: return k_tail<false, true, false>;
+        case 3: return k_tail<true, true, false>;
+        case 4: return k_tail<false, false, true>;
+        case 5: return k_tail<true, false, true>;
+        case 6: return k_tail<false, true, true>;
+        default: return k_tail<true, true, true>;
+    }
+}
+
 // ============================================================================================ launchers
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
-void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, ChunkCounters* cc, RenderCounters* rc) {
-    const ClosestArgs a{S, gen, rays, hits, hit_list, touched, cc, rc, bounce};
+void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, uint32_t tail_threshold, ChunkCounters* cc, RenderCounters* rc) {
+    const ClosestArgs a{S, gen, rays, hits, hit_list, touched, cc, rc, bounce, tail_threshold};
     if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
     else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
@@ -1488,6 +1621,11 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
     auto k = shade_variant(L.variant);
     const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, cc, rc, acc_stride, bounce, max_depth};
     hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
+}
+void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
+                 int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc) {
+    const TailArgs a{S, gen, {rays_even, rays_odd}, acc, cc, rc, acc_stride, max_depth, threshold};
+    hipLaunchKernelGGL(tail_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
 void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, spp, out_index, out_rgb);
@@ -1517,6 +1655,11 @@ int occupancy_blocks_closest(size_t lds_bytes, int variant) {
     hipError_t e = (variant & 4) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<true>, kBlock, lds_bytes)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<false>, kBlock, lds_bytes);
     if (e != hipSuccess) n = 2;
+    return clamp_blocks(n);
+}
+int occupancy_blocks_tail(size_t lds_bytes, int variant) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_variant(variant), kBlock, lds_bytes) != hipSuccess) n = 1;
     return clamp_blocks(n);
 }
 int occupancy_blocks_shade(size_t lds_bytes, int variant) {

@@ -122,6 +122,7 @@ typedef struct ft_stats {
     uint64_t hits_total;     /* hits shaded over all bounces                                   */
     uint64_t algorithmic_bytes_closest; /* the k_closest share of algorithmic_bytes            */
     uint64_t algorithmic_bytes_shade;   /* the k_shade share                                   */
+    uint64_t rays_tail;      /* reflection rays followed by the tail kernel (handed over + spawned inside it) */
 } ft_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -133,7 +134,8 @@ int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out
 void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);
 /* Tunables: "chunk_samples" (samples in flight per launch), "csg_mesh_capacity" (hit-list entries a mesh may add under
- * CSG), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
+ * CSG), "tail_rays" (a bounce starting with fewer rays is finished by the tail
+ * kernel in one launch; 0 = never; default 65536), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
 
@@ -203,7 +205,7 @@ int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[8]);
 int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9],
                        double above[18], int32_t* n_above, double below[18], int32_t* n_below);
 /* HIP-event time per stage over the last ft_render: index 0 accumulator clear (primary rays are generated inside bounce 0),
- * 1 closest, 2 shade, 3 blend. */
+ * 1 closest, 2 shade (and the tail kernel), 3 blend. */
 int32_t ft_get_kernel_times(ft_context* ctx, double ms[4], int32_t launches[4]);
 
 /* Image.write's toByte (Image.fs:36): clamp to [0,1], *255, truncate; alpha = 255. */

@@ -441,3 +441,26 @@ def test_image_textures_match_oracle(hip):
     want, _ = orc.render(cam, 160, 120, 2, jit)
     got, _ = hip.render(cam, 160, 120, 2, jit)
     assert H.assert_frames_match(got, want, what="image textures") < 1e-6
+
+
+@pytest.mark.parametrize("name", ["hollow-sphere", "night-house", "sample-soft"])
+def test_tail_kernel_changes_no_pixel_and_no_count(hip, name):
+    """k_tail finishes the late bounces in one launch: same device functions, same order per sample, so the frame and every
+    ray count must equal the staged bounces bit for bit wherever the hand-over happens."""
+    p = _load(name)
+    p.lower(hip)
+    jit = ft.jitter_pattern(2)
+    frames, stats = [], []
+    try:
+        for threshold in (0, 1 << 30, 3000):
+            hip.set_option("tail_rays", threshold)
+            img, st = hip.render(p.camera, 160, 90, 2, jit)
+            frames.append(img)
+            stats.append(st)
+    finally:
+        hip.set_option("tail_rays", 65536)
+    assert stats[0]["rays_tail"] == 0 and stats[1]["rays_tail"] > 0
+    for img, st in zip(frames[1:], stats[1:]):
+        assert np.array_equal(img, frames[0])
+        for key in ("rays_shadow", "rays_reflect", "rays_traced", "hits_total", "rays_reference_equivalent"):
+            assert st[key] == stats[0][key], key
