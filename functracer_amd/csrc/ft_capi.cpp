@@ -37,7 +37,7 @@ struct ft_context {
     fth::FlatScene flat;
     bool committed = false;
 
-    int64_t chunk_samples = 8ll << 20;
+    int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
     int64_t tail_rays = 65536;       // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM

@@ -213,7 +213,7 @@ def test_full_size_frame_properties(hip):
     assert np.array_equal(tiled, full), "union of tiles differs from the single-launch frame"
     hip.set_option("chunk_samples", 300000)
     chunked, st2 = hip.render(p.camera, w, h, 1, jit)
-    hip.set_option("chunk_samples", 8 << 20)
+    hip.set_option("chunk_samples", 16 << 20)
     assert st2["n_chunks"] > 1 and np.array_equal(chunked, full), "chunking changes the frame"
     assert np.isfinite(full).all()          # negative channels are legitimate: Lambert is unclamped (Shading.fs:69)
 
@@ -305,7 +305,7 @@ def test_seeded_soft_shadows_and_depth_of_field(hip, name, w, h, spp):
     hip.set_option("chunk_samples", 4096)
     hip.render(p.camera, w, h, spp, jit, seed=1234, tiles=[(0, 0, w, h // 2)], out=tiled)
     hip.render(p.camera, w, h, spp, jit, seed=1234, tiles=[(0, h // 2, w, h - h // 2)], out=tiled)
-    hip.set_option("chunk_samples", 8 << 20)
+    hip.set_option("chunk_samples", 16 << 20)
     assert np.array_equal(tiled, got)
 
 
@@ -324,7 +324,7 @@ def test_corner_sampling(hip, name):
     part = np.full_like(got, -7.0)
     hip.set_option("chunk_samples", 1000)                    # forces the corner grid to be split by rows
     hip.render(p.camera, w, h, 0, None, seed=5, tiles=[(8, 4, 40, 30), (60, 0, 12, 7)], out=part)
-    hip.set_option("chunk_samples", 8 << 20)
+    hip.set_option("chunk_samples", 16 << 20)
     mask = np.zeros((h, w), dtype=bool)
     mask[4:34, 8:48] = True; mask[0:7, 60:72] = True
     assert np.array_equal(part[mask], got[mask]) and (part[~mask] == -7.0).all()
