@@ -38,10 +38,11 @@ struct ft_context {
     bool committed = false;
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
+    bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
     int64_t tail_rays = 65536;       // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_active_ids, d_active_pos;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_touched, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
@@ -196,7 +197,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_out_index,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_active_ids, &c->d_active_pos, &c->d_out_index,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -212,6 +213,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!c || !key) return FT_ERR_INVALID;
     if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; for (ft_context* p : c->peers) p->chunk_samples = value; return FT_OK; }
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
+    if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
@@ -537,6 +539,14 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
     FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 1), c->stream));
 
+    // k_classify applies to pinhole cameras over whole 64-pixel blocks and scenes in which every top-level item is bounded
+    bool classify = c->classify_pixels && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && pix_per_chunk % 64 == 0;
+    for (size_t k = 0; classify && k + 1 < c->flat.item_pc.size(); ++k) if (!(c->flat.cull_items[8 * k + 3] < 1e30f)) classify = false;
+    for (const Job& j : jobs) if (j.n_ids % 64u) classify = false;
+    if (classify) {
+        if ((rc = ensure(c, c->d_active_ids, (size_t)pix_per_chunk * 4)) != FT_OK) return rc;
+        if ((rc = ensure(c, c->d_active_pos, (size_t)pix_per_chunk * 4)) != FT_OK) return rc;
+    }
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
     int variant = 0;
@@ -574,9 +584,15 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         const uint32_t n_pix = job.n_ids;
         const uint32_t n_samples = n_pix * (uint32_t)spp;
         timed(0, [&] { (void)hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream); });
-        const ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
-                               (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
-                               1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h)};
+        ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
+                         (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
+                         1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h), nullptr};
+        double* const chunk_out = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
+        if (classify) {
+            timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, gen, c->d_active_ids.as<uint32_t>(), c->d_active_pos.as<uint32_t>(), &cc->pixels, chunk_out, whole ? 1 : 0, rcount); });
+            n_launches += 2;
+            gen.pixel_ids = c->d_active_ids.as<uint32_t>(); gen.pix_base = 0; gen.counts = &cc->pixels;
+        }
         for (int b = 0; b <= last_bounce; ++b) {
             timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, (uint32_t)c->tail_rays, cc, rcount); });
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
@@ -587,9 +603,10 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
             ++n_launches;
         }
         const uint32_t* out_index = !whole ? nullptr : (corner ? c->d_out_index.as<uint32_t>() : c->d_pixels.as<uint32_t>()) + job.out_base;
-        double* out_ptr = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
+        if (classify) out_index = whole ? c->d_active_ids.as<uint32_t>() : c->d_active_pos.as<uint32_t>();
+        double* out_ptr = chunk_out;
         if (corner) timed(3, [&] { ftk::launch_blend_corner(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, job.w, job.h, out_index, out_ptr); });
-        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, spp, out_index, out_ptr); });
+        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, classify ? &cc->pixels : nullptr, spp, out_index, out_ptr); });
         ++n_launches;
     }
     timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, ftk::kStatSlots); });
@@ -614,17 +631,19 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         stats->kernel_ms = ms; stats->trace_kernel_ms = c->k_ms[1] + c->k_ms[2];
         {   // bytes the pipeline has to move by construction (ft_device.h); P primary rays, R reflection rays, H hits, H0 primary hits
             // rays and hits that k_tail handled never became records: Ti rays were handed to it (written once, read once), Tr spawned and Th shaded inside it
-            const uint64_t P = stats->rays_primary, Ti = hrc.tail_in, Tr = hrc.tail_rays, Th = hrc.tail_hits, RR = hrc.rays_reflect, HH = hrc.hits_total;
+            const uint64_t Pc = (uint64_t)hrc.pixels_culled * (uint64_t)spp, P = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, Pc), Ti = hrc.tail_in, Tr = hrc.tail_rays, Th = hrc.tail_hits, RR = hrc.rays_reflect, HH = hrc.hits_total;
             const uint64_t R = RR - std::min(RR, Ti + Tr), Rw = RR - std::min(RR, Tr);
             const uint64_t H = HH - std::min(HH, Th), H0 = hrc.hits_primary, HL = H - std::min(H, H0);
             stats->hits_total = hrc.hits_total;
             stats->rays_tail = Ti + Tr;
+            stats->rays_primary_culled = Pc;
             stats->algorithmic_bytes_closest = P * (ftk::kPixelIdBytes + ftk::kTouchedBytes) + R * 48 + H * (ftk::kHitRecBytes + ftk::kListBytes);
             stats->algorithmic_bytes_shade = H * (ftk::kHitRecBytes + ftk::kListBytes) + H0 * (2 * ftk::kPixelIdBytes + ftk::kAccBytes) +
                                              HL * (48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + Rw * ftk::kRayRecBytes;
             stats->algorithmic_bytes = stats->algorithmic_bytes_closest + stats->algorithmic_bytes_shade +
                                        Ti * ftk::kRayRecBytes + Th * 2 * ftk::kAccBytes +                       // + k_tail
-                                       P * ftk::kTouchedBytes + H0 * ftk::kAccBytes + 24ull * (uint64_t)n_pix_total;   // + k_blend
+                                       P * ftk::kTouchedBytes + H0 * ftk::kAccBytes + 24ull * (uint64_t)n_pix_total +   // + k_blend (and the pixels k_classify wrote)
+                                       (classify ? (uint64_t)n_pix_total * ftk::kPixelIdBytes + (P / (uint64_t)spp) * 2 * ftk::kPixelIdBytes : 0ull);   // + k_classify
         }
         stats->n_launches = n_launches; stats->n_chunks = n_chunks;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();

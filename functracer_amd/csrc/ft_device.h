@@ -47,8 +47,11 @@ constexpr uint64_t kRayRecBytes = 60, kHitRecBytes = 16;
 // read once; an accumulator 24 B stored (bounce 0) or read-modify-written (later bounces); a pixel 24 B out.
 constexpr uint64_t kPixelIdBytes = 4, kTouchedBytes = 1, kListBytes = 4, kAccBytes = 24;
 
+// Pixels of a chunk that are actually traced (k_classify): count and its reciprocal (division-free index arithmetic).
+struct PixCount { uint32_t n_pix, pad; double inv_n_pix; };
 // Per-chunk device counters (zeroed before every chunk).
 struct ChunkCounters {
+    PixCount pixels;
     uint32_t n_rays[kMaxBounce + 2];   // rays queued for bounce k
     uint32_t n_hits[kMaxBounce + 2];   // compacted lit/unlit hit count of bounce k
     // Work cursors: kWorkGroups independent counters per kernel and bounce, one 64-byte line each (see ft_kernels.hip).
@@ -61,6 +64,7 @@ struct RenderCounters {
     double ref_equiv;
     unsigned long long hits_total;      // hits shaded over all bounces
     unsigned long long tail_in, tail_rays, tail_hits;   // k_tail: rays handed over, reflection rays it spawned, hits it shaded
+    unsigned long long pixels_culled;                   // k_classify: pixels whose every primary ray provably misses everything
 };
 
 struct Camera {                    // ImagePlane (Image.fs:55-63), computed on the host
@@ -88,6 +92,7 @@ struct Primary {
     uint32_t stride;               // ids are y*stride + x: res_h for pixels, res_h + 1 for the corner grid of `samples corner`
     unsigned long long seed;       // keys the counter-based streams of soft shadows / depth of field
     double inv_n_pix, inv_stride;  // 1.0 / n_pix, 1.0 / stride (division-free index arithmetic, see div_by)
+    const PixCount* counts;        // non-null: pixel_ids is the chunk's ACTIVE pixel list (k_classify) and these replace n_pix / inv_n_pix
 };
 // K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.  Bounce 0 also records, one
 // byte per sample, whether the primary ray hit anything (`touched`): untouched samples are Colour.Zero and their accumulator is
@@ -95,6 +100,11 @@ struct Primary {
 void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, uint32_t tail_threshold,
                     ChunkCounters* cc, RenderCounters* rc);
 // K3: shading + shadow rays + accumulation for the compacted hits of bounce k; emits bounce k+1 rays.
+// K1: pixel-block classification.  A block of 64 pixels (all its samples) whose ray bundle cannot reach any top-level item is
+// finished on the spot (its output pixels are written as Colour.Zero); the others are compacted into the chunk's active
+// pixel list, which is all the later stages see.
+void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint32_t* active_ids, uint32_t* active_pos, PixCount* counts,
+                     double* out, int whole, RenderCounters* rc);
 // Tail of the bounce loop (k_tail): once a bounce has fewer than `threshold` rays the per-bounce stages stand down and this one
 // launch follows every remaining path to its end inside registers.
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
@@ -104,7 +114,7 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
                   double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
 // out_index == nullptr: pixel p is written at out_rgb + 3p (packed); else at out_rgb + 3*out_index[p] (in place in the frame).
-void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb);
+void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, int32_t spp, const uint32_t* out_index, double* out_rgb);
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
 void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
 // Sum the per-wave statistic slots 1..n_slots into slot 0 (one block).

@@ -628,6 +628,36 @@ FT_DEV float wave_min(float v) {                                    // all 64 la
     return fminf(fminf(a, b), fminf(c, d));
 }
 struct ItemMask { unsigned long long lo, hi; bool valid; };   // bit k: top-level item k may be hit by some ray of the wave (items >= 128: not covered)
+// A bundle of rays bounded by a cone: apex c (origins within rho of it), unit axis a, half-angle given by cos_t (rounded down) /
+// sin_t (rounded up); par_rows = face directions some ray of the bundle may be nearly parallel to.
+struct Cone { float ax, ay, az, cx, cy, cz, cos_t, sin_t, rho; uint32_t par_rows; };
+// Lane k tests top-level ITEM k: bit k of the result is clear only when no ray inside the cone can give a usable hit on it.
+FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B) {
+    ItemMask M{~0ull, ~0ull, true};
+    const float origin_mag = fabsf(B.cx) + fabsf(B.cy) + fabsf(B.cz);
+    const int n_pass = S.n_items > 64 ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int item = pass * 64 + (int)lane_id();
+        bool keep = true;
+        if (item < S.n_items) {
+            const float* I = S.cull_items + 8 * item;
+            const float vx = I[0] - B.cx, vy = I[1] - B.cy, vz = I[2] - B.cz;
+            const uint32_t rows = __float_as_uint(I[4]);
+            const float slack = 1e-5f * (1.0f + origin_mag + fabsf(I[0]) + fabsf(I[1]) + fabsf(I[2]));
+            const float reach = I[3] * 1.0001f + B.rho + slack;     // sphere radius + origin spread + rounding slack
+            const float h = vx * B.ax + vy * B.ay + vz * B.az;
+            const float w = sqrtf(fmaxf(0.0f, (vx * vx + vy * vy + vz * vz) - h * h));
+            // lower bound of the distance from the centre to the cone: beyond its nearest tangent plane in front of the apex;
+            // behind the apex the cone also lies within the half-space (x - apex).axis >= 0
+            const float beyond = h > 0.0f ? w * B.cos_t - h * B.sin_t : fmaxf(w * B.cos_t, -h);
+            keep = !(beyond > reach) || (rows & B.par_rows) != 0u;
+        }
+        const unsigned long long km = __ballot(keep && item < S.n_items);
+        if (pass == 0) M.lo = km; else M.hi = km;
+    }
+    if (n_pass == 1) M.hi = 0ull;
+    return M;
+}
 FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     ItemMask M{~0ull, ~0ull, false};
     if (S.n_items < 3 || S.n_cull_rows < 0) return M;
@@ -652,36 +682,13 @@ FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     if (!(cos_t > 0.3f) || !(rho2 < 1e30f)) return M;               // a wide bundle bounds nothing
     const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f;   // sine of the widened half-angle, rounded up
     const float rho = sqrtf(rho2) * 1.0001f;
-    const float origin_mag = fabsf(cx) + fabsf(cy) + fabsf(cz);
     // rays of the wave nearly parallel to a face direction: items using that direction are kept (exact FP64 test as in OP_CULL)
     uint32_t par_rows = 0;
     for (int k = 0; k < S.n_cull_rows; ++k) {
         cdp Rw = S.cull_rows + 3u * (uint32_t)k;
         if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
     }
-    const int n_pass = S.n_items > 64 ? 2 : 1;
-    for (int pass = 0; pass < n_pass; ++pass) {
-        const int item = pass * 64 + (int)lane_id();
-        bool keep = true;
-        if (item < S.n_items) {
-            const float* I = S.cull_items + 8 * item;
-            const float vx = I[0] - cx, vy = I[1] - cy, vz = I[2] - cz;
-            const uint32_t rows = __float_as_uint(I[4]);
-            const float slack = 1e-5f * (1.0f + origin_mag + fabsf(I[0]) + fabsf(I[1]) + fabsf(I[2]));
-            const float reach = I[3] * 1.0001f + rho + slack;       // sphere radius + origin spread + rounding slack
-            const float h = vx * ax + vy * ay + vz * az;
-            const float w = sqrtf(fmaxf(0.0f, (vx * vx + vy * vy + vz * vz) - h * h));
-            // lower bound of the distance from the centre to the cone: beyond its nearest tangent plane in front of the apex;
-            // behind the apex the cone also lies within the half-space (x - apex).axis >= 0
-            const float beyond = h > 0.0f ? w * cos_t - h * sin_t : fmaxf(w * cos_t, -h);
-            keep = !(beyond > reach) || (rows & par_rows) != 0u;
-        }
-        const unsigned long long km = __ballot(keep && item < S.n_items);
-        if (pass == 0) M.lo = km; else M.hi = km;
-    }
-    if (n_pass == 1) M.hi = 0ull;
-    M.valid = true;
-    return M;
+    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows});
 }
 
 // Exact skip test of one top-level item for this lane's ray (see OP_CULL).
@@ -1042,8 +1049,17 @@ struct JitterFrame {
 // and quotient * b < 2^32 (four FP64 instructions in place of the ~25 of an integer division).
 FT_DEV uint32_t div_by(uint32_t a, double inv_b) { return (uint32_t)(((double)a + 0.5) * inv_b); }
 
+// Pixels per sample plane of the chunk: the active count written by k_classify, or the host's when nothing was classified.
+struct Pix { uint32_t n; double inv; };
+FT_DEV Pix pix_count(PrimaryArg g) {
+    const PixCount* c = g->counts;
+    if (c) { const FT_CONST PixCount* cc = to_const_as(c); return {cc->n_pix, cc->inv_n_pix}; }
+    return {g->n_pix, g->inv_n_pix};
+}
+
 FT_DEV unsigned long long sample_id(PrimaryArg g, uint32_t slot) {
-    const uint32_t s = div_by(slot, g->inv_n_pix), pl = slot - s * g->n_pix;
+    const Pix px = pix_count(g);
+    const uint32_t s = div_by(slot, px.inv), pl = slot - s * px.n;
     return (unsigned long long)g->pixel_ids[g->pix_base + pl] * (unsigned long long)g->spp + s;
 }
 
@@ -1051,13 +1067,14 @@ FT_DEV unsigned long long sample_id(PrimaryArg g, uint32_t slot) {
 // (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
 // 64 pixels of one 8x8 block for one jitter offset).
 FT_DEV uint32_t primary_pixel(PrimaryArg g, uint32_t i) {            // the one memory access a primary ray needs
-    const uint32_t s = div_by(i, g->inv_n_pix), pl = i - s * g->n_pix;
+    const Pix px = pix_count(g);
+    const uint32_t s = div_by(i, px.inv), pl = i - s * px.n;
     return g->pixel_ids[g->pix_base + pl];
 }
 // `uniform_s`: all 64 lanes of the batch share one jitter offset (n_pix is a multiple of 64): it is then read
 // through a scalar load, which does not queue behind the wave's outstanding vector stores.
 FT_DEV Ray primary_ray_from(PrimaryArg g, uint32_t i, uint32_t pid, bool uniform_s) {
-    const uint32_t s = div_by(i, g->inv_n_pix);
+    const uint32_t s = div_by(i, pix_count(g).inv);
     const uint32_t py = div_by(pid, g->inv_stride), px = pid - py * g->stride;
     const double centre_x = g->cam.tlx + (double)px * g->cam.pw, centre_y = g->cam.tly - (double)py * g->cam.ph;
     double ox, oy;
@@ -1092,7 +1109,7 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
     const Scene S = scene_view(K->S);
     const int bounce = K->bounce;
     ChunkCounters* cc = K->cc;
-    const uint32_t n_pix = K->gen.n_pix;
+    const uint32_t n_pix = pix_count(&K->gen).n;
     const uint32_t n = bounce == 0 ? n_pix * (uint32_t)K->gen.spp : cc->n_rays[bounce];
     if (bounce > 0 && n < K->tail_threshold) return;               // few rays left: k_tail follows them to the end (nothing is spawned after this bounce)
     const uint32_t B = batch_lanes_for(n);
@@ -1392,6 +1409,107 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_classify: which 64-pixel blocks of the chunk can see anything at all.  One wave per block: lane = pixel; the cone around
+// the block's primary rays - ALL samples of its pixels: every jitter offset lies in the unit disc (Jitter.fs:15-21), so the
+// four rays through the corners (+-1, +-1) pixel around each pixel centre bound them - is tested against the bounding
+// sphere of every top-level item (items_in_cone, conservative).  A block no item can be hit from is finished here: its
+// pixels are written as Colour.Zero (Scene.fs:116, no hit) and none of its W*H*spp rays is generated.  The other blocks are
+// appended to the chunk's active pixel list, in blocks of 64 so a wavefront stays one compact bundle.  The host only runs
+// this for pinhole cameras over whole 64-pixel blocks and scenes made of bounded items.
+struct ClassifyArgs {
+    DevScene S; Primary gen;                                        // gen.pixel_ids / pix_base / n_pix: the chunk's full pixel list
+    uint32_t* active_ids; uint32_t* active_pos; PixCount* counts; double* out; RenderCounters* rc; int32_t whole;
+};
+constexpr uint32_t kClassifyRun = 8;                                // consecutive blocks per wave: one list reservation for all of them
+
+__global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
+    const FT_CONST ClassifyArgs* K = kernel_args<ClassifyArgs>();
+    const Scene S = scene_view(K->S);
+    const PrimaryArg g = &K->gen;
+    const uint32_t n_blocks = g->n_pix / 64u;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64, n_waves = gridDim.x * (kBlock / 64);
+    unsigned long long culled = 0ull;
+    for (uint32_t run = wave * kClassifyRun; run < n_blocks; run += n_waves * kClassifyRun) {
+        uint32_t keep_mask = 0u;                                    // bit j: block run + j is active
+        uint32_t pid_of[kClassifyRun];
+#pragma unroll
+        for (uint32_t j = 0; j < kClassifyRun; ++j) {
+            const uint32_t blk = run + j;
+            pid_of[j] = 0u;
+            if (blk >= n_blocks) continue;                          // wave-uniform
+            const uint32_t pid = g->pixel_ids[g->pix_base + blk * 64u + lane_id()];
+            pid_of[j] = pid;
+            const uint32_t py = div_by(pid, g->inv_stride), px = pid - py * g->stride;
+            const double cxp = g->cam.tlx + (double)px * g->cam.pw, cyp = g->cam.tly - (double)py * g->cam.ph;
+            float cos_dev = 1.0f, ax = 0.f, ay = 0.f, az = 0.f;
+            double dlo[3], dhi[3];                                  // per-lane range of the ray direction over the pixel's jitter square
+            bool finite = true;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {                           // centre, then the four corners
+                const double ox = c == 0 ? 0.0 : ((c & 1) ? 1.000001 : -1.000001), oy = c == 0 ? 0.0 : ((c & 2) ? 1.000001 : -1.000001);
+                const double jx = cxp + ox * g->cam.pw, jy = cyp + oy * g->cam.ph;
+                const double dx = (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0], dy = (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1],
+                             dz = (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2];
+                float fx = (float)dx, fy = (float)dy, fz = (float)dz;
+                const float l2 = fx * fx + fy * fy + fz * fz;
+                finite = finite && l2 > 1e-30f && l2 < 1e30f;
+                const float inv = __builtin_amdgcn_rsqf(l2);
+                fx *= inv; fy *= inv; fz *= inv;
+                if (c == 0) {                                       // axis: the centre ray of the block's first pixel
+                    ax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fx))); ay = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fy)));
+                    az = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fz)));
+                    dlo[0] = dhi[0] = dx; dlo[1] = dhi[1] = dy; dlo[2] = dhi[2] = dz;
+                } else {
+                    cos_dev = fminf(cos_dev, ax * fx + ay * fy + az * fz);
+                    dlo[0] = fmin(dlo[0], dx); dhi[0] = fmax(dhi[0], dx); dlo[1] = fmin(dlo[1], dy); dhi[1] = fmax(dhi[1], dy); dlo[2] = fmin(dlo[2], dz); dhi[2] = fmax(dhi[2], dz);
+                }
+            }
+            bool active = true;
+            const float cos_t = wave_min(cos_dev) - 1e-5f;
+            if (!__any(!finite) && cos_t > 0.3f) {
+                // face directions some ray of the block may be nearly parallel to (Plane.fs:13-16): d is affine in the jitter, so
+                // row . d over the pixel's square lies between the sums of the per-component extremes
+                uint32_t par_rows = 0;
+                for (int k = 0; k < S.n_cull_rows; ++k) {
+                    cdp Rw = S.cull_rows + 3u * (uint32_t)k;
+                    double lo = 0.0, hi = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { const double u = Rw[a] * dlo[a], v = Rw[a] * dhi[a]; lo += fmin(u, v); hi += fmax(u, v); }
+                    if (__any(lo < 2.000001 * kEps && hi > -2.000001 * kEps)) par_rows |= 1u << k;
+                }
+                const Cone B{ax, ay, az, (float)g->cam.o[0], (float)g->cam.o[1], (float)g->cam.o[2], cos_t, sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f,
+                             1e-5f * (1.0f + fabsf((float)g->cam.o[0]) + fabsf((float)g->cam.o[1]) + fabsf((float)g->cam.o[2])), par_rows};
+                const ItemMask M = items_in_cone(S, B);
+                active = (M.lo | M.hi) != 0ull || S.n_items > 128;
+            }
+            if (active) keep_mask |= 1u << j;
+            else {                                                  // finished: Colour.Zero for every pixel of the block
+                culled += 64ull;
+                const size_t o = K->whole ? (size_t)pid : (size_t)(blk * 64u + lane_id());
+                double* out = K->out;
+                out[3 * o] = 0.0; out[3 * o + 1] = 0.0; out[3 * o + 2] = 0.0;
+            }
+        }
+        const uint32_t n_keep = (uint32_t)__popc(keep_mask);
+        if (n_keep) {
+            uint32_t base = 0;
+            if (lane_id() == 0) base = atomicAdd(&K->counts->n_pix, 64u * n_keep);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (uint32_t j = 0; j < kClassifyRun; ++j) {
+                if (!((keep_mask >> j) & 1u)) continue;
+                K->active_ids[base + lane_id()] = pid_of[j];
+                K->active_pos[base + lane_id()] = (run + j) * 64u + lane_id();
+                base += 64u;
+            }
+        }
+    }
+    wave_add(&my_stats(K->rc)->pixels_culled, culled);
+}
+// The reciprocal of the active count, once the count is final.
+__global__ void k_classify_finish(PixCount* counts) { counts->inv_n_pix = 1.0 / (double)counts->n_pix; }
+
+// ---------------------------------------------------------------------------------------------
 // k_tail: the end of the bounce loop as one launch.  Late bounces carry few, incoherent rays; run as closest / shade stages
 // each of them costs two launches whose time is the latency of a single batch (~30-100 us: every stage boundary sends the
 // ray and hit records through HBM, across XCDs).  Once a bounce k >= 1 starts with fewer than `threshold` rays, k_closest
@@ -1487,10 +1605,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_tail(TailArgs) {
 
 __global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, uint32_t n_slots) {   // one block; slot 0 receives the totals
     __shared__ RenderCounters part[kBlock];
-    RenderCounters s{0, 0, 0, 0, 0.0, 0, 0, 0, 0};
+    RenderCounters s{0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0};
     for (uint32_t k = 1 + threadIdx.x; k <= n_slots; k += kBlock) {
         s.rays_shadow += slots[k].rays_shadow; s.rays_reflect += slots[k].rays_reflect; s.hits_primary += slots[k].hits_primary;
-        s.tail_in += slots[k].tail_in; s.tail_rays += slots[k].tail_rays; s.tail_hits += slots[k].tail_hits;
+        s.tail_in += slots[k].tail_in; s.tail_rays += slots[k].tail_rays; s.tail_hits += slots[k].tail_hits; s.pixels_culled += slots[k].pixels_culled;
         s.csg_overflow += slots[k].csg_overflow; s.ref_equiv += slots[k].ref_equiv; s.hits_total += slots[k].hits_total;
     }
     part[threadIdx.x] = s;
@@ -1499,15 +1617,16 @@ __global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, 
         RenderCounters t = slots[0];                              // debug kernels add to slot 0 directly
         for (int k = 0; k < kBlock; ++k) {
             t.rays_shadow += part[k].rays_shadow; t.rays_reflect += part[k].rays_reflect; t.hits_primary += part[k].hits_primary;
-            t.tail_in += part[k].tail_in; t.tail_rays += part[k].tail_rays; t.tail_hits += part[k].tail_hits;
+            t.tail_in += part[k].tail_in; t.tail_rays += part[k].tail_rays; t.tail_hits += part[k].tail_hits; t.pixels_culled += part[k].pixels_culled;
             t.csg_overflow += part[k].csg_overflow; t.ref_equiv += part[k].ref_equiv; t.hits_total += part[k].hits_total;
         }
         slots[0] = t;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, const uint8_t* __restrict__ touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp,
-                                                   const uint32_t* __restrict__ out_index, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, const uint8_t* __restrict__ touched, uint32_t acc_stride, uint32_t n_pix_host, const PixCount* counts,
+                                                   int32_t spp, const uint32_t* __restrict__ out_index, double* __restrict__ out) {
+    const uint32_t n_pix = counts ? counts->n_pix : n_pix_host;     // active pixels of the chunk (k_classify) or all of them
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
         double r = 0.0, g = 0.0, b = 0.0;                          // Array.average: sum from Zero in sample order, then DivideByInt
         for (int s = 0; s < spp; ++s) {
@@ -1622,13 +1741,20 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
     const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, cc, rc, acc_stride, bounce, max_depth};
     hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
+void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint32_t* active_ids, uint32_t* active_pos, PixCount* counts,
+                     double* out, int whole, RenderCounters* rc) {
+    const ClassifyArgs a{S, gen_list, active_ids, active_pos, counts, out, rc, whole};
+    const uint32_t n_runs = (gen_list.n_pix / 64u + kClassifyRun - 1) / kClassifyRun;
+    hipLaunchKernelGGL(k_classify, dim3(blocks_for(n_runs * 64u, L.grid)), dim3(kBlock), 0, L.stream, a);
+    hipLaunchKernelGGL(k_classify_finish, dim3(1), dim3(1), 0, L.stream, counts);
+}
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
                  int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc) {
     const TailArgs a{S, gen, {rays_even, rays_odd}, acc, cc, rc, acc_stride, max_depth, threshold};
     hipLaunchKernelGGL(tail_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
-void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, int32_t spp, const uint32_t* out_index, double* out_rgb) {
-    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, spp, out_index, out_rgb);
+void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, int32_t spp, const uint32_t* out_index, double* out_rgb) {
+    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, counts, spp, out_index, out_rgb);
 }
 void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, w, h, out_index, out_rgb);

@@ -123,6 +123,8 @@ typedef struct ft_stats {
     uint64_t algorithmic_bytes_closest; /* the k_closest share of algorithmic_bytes            */
     uint64_t algorithmic_bytes_shade;   /* the k_shade share                                   */
     uint64_t rays_tail;      /* reflection rays followed by the tail kernel (handed over + spawned inside it) */
+    uint64_t rays_primary_culled; /* primary rays (part of rays_primary) resolved as misses per 64-pixel block: the block's ray
+                                   * bundle cannot reach any object, so they were never generated one by one          */
 } ft_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -134,7 +136,8 @@ int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out
 void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);
 /* Tunables: "chunk_samples" (samples in flight per launch), "csg_mesh_capacity" (hit-list entries a mesh may add under
- * CSG), "tail_rays" (a bounce starting with fewer rays is finished by the tail
+ * CSG), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
+ * cannot reach any object are finished before any ray is generated), "tail_rays" (a bounce starting with fewer rays is finished by the tail
  * kernel in one launch; 0 = never; default 65536), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);

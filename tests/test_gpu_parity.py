@@ -464,3 +464,28 @@ def test_tail_kernel_changes_no_pixel_and_no_count(hip, name):
         assert np.array_equal(img, frames[0])
         for key in ("rays_shadow", "rays_reflect", "rays_traced", "hits_total", "rays_reference_equivalent"):
             assert st[key] == stats[0][key], key
+
+
+@pytest.mark.parametrize("name", ["bunny", "moon", "hollow-sphere", "bunny-bsp12"])
+def test_pixel_block_classification_changes_no_pixel(hip, name):
+    """k_classify finishes 64-pixel blocks that cannot see any object before a single ray is generated: the frame, the hit
+    counts and the ray counts must not notice, whole frame or tiles."""
+    p = _load(name)
+    p.lower(hip)
+    jit = ft.jitter_pattern(3)
+    w, h = 256, 192
+    tiles = [(0, 0, 128, 192), (128, 64, 128, 128), (128, 0, 64, 64)]
+    out = {}
+    try:
+        for on in (0, 1):
+            hip.set_option("classify_pixels", on)
+            out[on] = hip.render(p.camera, w, h, 3, jit) + hip.render(p.camera, w, h, 3, jit, tiles=tiles)
+    finally:
+        hip.set_option("classify_pixels", 1)
+    (f0, s0, t0, st0), (f1, s1, t1, st1) = out[0], out[1]
+    assert np.array_equal(f0, f1) and np.array_equal(t0, t1)
+    assert s0["rays_primary_culled"] == 0
+    if name != "hollow-sphere":                                   # its camera sits inside the shell: every block sees it
+        assert s1["rays_primary_culled"] > 0 and st1["rays_primary_culled"] > 0
+    for key in ("rays_primary", "rays_shadow", "rays_reflect", "rays_traced", "hits_primary", "hits_total", "rays_reference_equivalent"):
+        assert s0[key] == s1[key] and st0[key] == st1[key], key
