@@ -26,6 +26,8 @@ struct DevScene {
     const double* tris;            // 9 per triangle: v0, e1, e2
     const double* culls;           // 24 doubles per ftd::CullRecord
     const uint32_t* tri_orig;      // 1 per triangle
+    const double* wide;            // 28 doubles per 4-wide BVH node (ft_flat.h)
+    const int32_t* mesh_wide;      // per mesh: root of its 4-wide BVH or INT32_MIN
     const uint8_t* tex_pixels;     // Rgb24 rows of the image textures (ftd::Texture::pixel_base indexes into it)
     const float* cull_items;       // 8 floats per top-level item (centre, radius, row mask): wave-level pre-test of the item culls
     const uint32_t* item_pc;       // n_items + 1 program counters: where each top-level item starts (last: the OP_END word)

@@ -82,6 +82,12 @@ struct Mesh {
     uint32_t max_depth;    // BspMesh.maxDepth of the compiled tree
     int32_t bvh_root;      // top-level-Leaf meshes only: root of the device-side BVH (>= 0 node, < 0 ~leaf), or INT32_MIN = none
 };
+// 4-wide BVH node for packet traversal (28 doubles): the boxes of up to four children live in the PARENT, so one scalar-load
+// round trip decides four subtrees (the two children of each child of a binary BVH node, collapsed):
+//   [6*c .. 6*c+5] = lo xyz, hi xyz of child c (c = 0,1: the left half; 2,3: the right half)
+//   [24], [25]     = int32 child[4]: >= 0 wide node, < 0 ~leaf index, INT32_MIN empty slot
+//   [26]           = uint32 axes: split axis of the binary node | of its left child << 8 | of its right child << 16
+constexpr int kWideNodeDoubles = 28;
 struct BspNode {           // 64 bytes; BspMesh.fs:12-19 (also used for BVH nodes)
     double bmin[3], bmax[3];
     int32_t left, right;   // >= 0 branch node; < 0: ~leaf index

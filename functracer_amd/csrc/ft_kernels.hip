@@ -80,6 +80,8 @@ struct Scene {
     cdp tris;         // 9 doubles per triangle
     cdp culls;        // 24 doubles per ftd::CullRecord
     cup tri_orig;     // 1 per triangle
+    cdp wide;         // 28 doubles per 4-wide BVH node
+    cip mesh_wide;    // 1 per mesh
     const uint8_t* tex_pixels;   // per-lane byte gathers: ordinary global loads
     const float* cull_items;     // lane k reads record k: ordinary global loads
     cdp cull_rows;
@@ -94,7 +96,7 @@ template <class DS> FT_DEV Scene scene_view(const DS& g) {
     s.textures = to_const_as(reinterpret_cast<const double*>(g.textures));
     s.program = to_const_as(g.program); s.meshes = to_const_as(reinterpret_cast<const int32_t*>(g.meshes));
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
-    s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig);
+    s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig); s.wide = to_const_as(g.wide); s.mesh_wide = to_const_as(g.mesh_wide);
     s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
     s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
     return s;
@@ -550,40 +552,54 @@ FT_DEV void mesh_bsp_query(const Scene& S, int32_t root, const Ray& r, Query<ANY
 // would have pruned a node on their own only run tests that cannot produce a usable hit for them (a
 // triangle lies inside its boxes), so the per-ray result equals mesh_bvh_query's.
 template <bool ANY>
-FT_DEV void mesh_bvh_packet(const Scene& S, int32_t bvh_root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit) {
+FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit) {
     bool alive = q.active && !(ANY && q.blocked);
     if (!__any(alive)) return;
     const double ivx = 1.0 / r.dx, ivy = 1.0 / r.dy, ivz = 1.0 / r.dz;
     double bound = ANY ? q.max_dist : q.best_t;
     uint32_t best_tri = 0xFFFFFFFFu;
     bool found = false;
-    int stack_lanes = 0;                                           // lane i holds stack entry i (depth <= 64)
+    int stack_lanes = 0;                                           // lane i holds stack entry i (at most 3 per level of the wide tree)
     int sp = 0;
-    int cur = bvh_root;
+    int cur = wide_root;
+    // The boxes of a node's four children live in the node (ft_flat.h): one scalar-load round trip decides four subtrees.
+    const unsigned long long live0 = __ballot(alive);
+    const bool fwd[3] = {2 * __popcll(__ballot(alive && r.dx >= 0.0)) >= __popcll(live0), 2 * __popcll(__ballot(alive && r.dy >= 0.0)) >= __popcll(live0),
+                         2 * __popcll(__ballot(alive && r.dz >= 0.0)) >= __popcll(live0)};   // majority direction per axis: which child is nearer
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         if (cur >= 0) {
-            cdp nd = S.nodes + 8ull * (uint32_t)cur;
-            double t0 = (nd[0] - r.ox) * ivx, t1 = (nd[3] - r.ox) * ivx;
-            double tmin = fmin(t0, t1), tmax = fmax(t0, t1);
-            t0 = (nd[1] - r.oy) * ivy; t1 = (nd[4] - r.oy) * ivy;
-            tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
-            t0 = (nd[2] - r.oz) * ivz; t1 = (nd[5] - r.oz) * ivz;
-            tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
-            const bool enter = alive && tmax >= fmax(tmin, 0.0) && tmin <= bound;
-            const unsigned long long m = __ballot(enter);
-            if (m) {
-                cip ch = reinterpret_cast<cip>(nd + 6);
-                const uint32_t axis = reinterpret_cast<cup>(nd + 7)[0];
-                const double da = axis == 0 ? r.dx : axis == 1 ? r.dy : r.dz;
-                const unsigned long long fwd = __ballot(enter && da >= 0.0);
-                const bool left_first = 2 * __popcll(fwd) >= __popcll(m);     // majority vote on the near child
-                const int near = left_first ? ch[0] : ch[1], far = left_first ? ch[1] : ch[0];
-                stack_lanes = ((int)lane_id() == sp) ? far : stack_lanes;   // "writelane": one compare + select
-                ++sp;
-                cur = near;
-                continue;
+            cdp nd = S.wide + (unsigned long long)kWideNodeDoubles * (uint32_t)cur;
+            cip ch = reinterpret_cast<cip>(nd + 24);
+            const uint32_t axes = reinterpret_cast<cup>(nd + 26)[0];
+            unsigned long long m[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                cdp bx = nd + 6 * c;
+                double t0 = (bx[0] - r.ox) * ivx, t1 = (bx[3] - r.ox) * ivx;
+                double tmin = fmin(t0, t1), tmax = fmax(t0, t1);
+                t0 = (bx[1] - r.oy) * ivy; t1 = (bx[4] - r.oy) * ivy;
+                tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+                t0 = (bx[2] - r.oz) * ivz; t1 = (bx[5] - r.oz) * ivz;
+                tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+                const bool enter = alive && tmax >= fmax(tmin, 0.0) && tmin <= bound;
+                m[c] = ch[c] == INT32_MIN ? 0ull : __ballot(enter);
             }
+            // visiting order, nearest first by the majority directions: halves by the node's axis, slots within a half by the child's
+            const bool left_half_first = fwd[axes & 3u], l_fwd = fwd[(axes >> 8) & 3u], r_fwd = fwd[(axes >> 16) & 3u];
+            const int l0 = l_fwd ? 0 : 1, l1 = l_fwd ? 1 : 0, r0 = r_fwd ? 2 : 3, r1 = r_fwd ? 3 : 2;
+            const int seq[4] = {left_half_first ? l0 : r0, left_half_first ? l1 : r1, left_half_first ? r0 : l0, left_half_first ? r1 : l1};
+            int next = kDone;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {                          // far to near: what was nearest so far goes on the stack
+                const int c = seq[j];
+                const unsigned long long mc = c == 0 ? m[0] : c == 1 ? m[1] : c == 2 ? m[2] : m[3];
+                if (mc) {
+                    if (next != kDone) { stack_lanes = ((int)lane_id() == sp) ? next : stack_lanes; ++sp; }
+                    next = c == 0 ? ch[0] : c == 1 ? ch[1] : c == 2 ? ch[2] : ch[3];
+                }
+            }
+            if (next != kDone) { cur = next; continue; }
         } else {
             const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
             for (uint32_t k = 0; k < count; ++k) {                 // wave-uniform: scalar loads
@@ -764,7 +780,7 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                     if (bvh >= 0) {
                         Ray rm;
                         to_model(S.leaves + 16ull * arg, (H.flags & LF_XFORM) != 0, r, rm);
-                        if (coherent) mesh_bvh_packet<ANY>(S, bvh, rm, q, arg, lit);
+                        if (coherent) mesh_bvh_packet<ANY>(S, S.mesh_wide[H.mesh], rm, q, arg, lit);
                         else mesh_bvh_query<ANY>(S, bvh, rm, q, arg, lit, stack);
                         break;
                     }

@@ -490,6 +490,9 @@ struct BspBuilder {
                 out.tris.insert(out.tris.end(), rec, rec + 9);
             }
             out.bsp_leaves.push_back(L);
+            Box lb{{1e308, 1e308, 1e308}, {-1e308, -1e308, -1e308}};            // the leaf's own (inflated) box, for the 4-wide nodes
+            for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) { lb.lo[a] = std::min(lb.lo[a], boxes[idx[k]].lo[a] - pad); lb.hi[a] = std::max(lb.hi[a], boxes[idx[k]].hi[a] + pad); }
+            leaf_box[out.bsp_leaves.size() - 1] = lb;
             return ~(int32_t)(out.bsp_leaves.size() - 1);
         }
         const double inf = std::numeric_limits<double>::infinity();
@@ -519,6 +522,33 @@ struct BspBuilder {
         for (int a = 0; a < 3; ++a) { nd.bmin[a] = b.lo[a] - pad; nd.bmax[a] = b.hi[a] + pad; }   // inflated: pruning can never drop a real hit
         nd.left = l; nd.right = r; nd.axis = (uint32_t)axis;
         return node;
+    }
+    // Collapse the binary BVH two levels at a time into 4-wide nodes whose child boxes sit in the parent (ft_flat.h).
+    std::map<size_t, Box> leaf_box;
+    Box box_of(int32_t child) const {
+        if (child < 0) return leaf_box.at((size_t)~child);
+        const ftd::BspNode& nd = out.nodes[(size_t)child];
+        return Box{{nd.bmin[0], nd.bmin[1], nd.bmin[2]}, {nd.bmax[0], nd.bmax[1], nd.bmax[2]}};
+    }
+    int32_t widen(int32_t n) {
+        const size_t at = out.wide.size();
+        out.wide.resize(at + ftd::kWideNodeDoubles, 0.0);
+        int32_t child[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+        Box box[4] = {};
+        uint32_t axes = out.nodes[(size_t)n].axis;
+        const int32_t halves[2] = {out.nodes[(size_t)n].left, out.nodes[(size_t)n].right};
+        for (int h = 0; h < 2; ++h) {
+            const int32_t c = halves[h];
+            if (c < 0) { child[2 * h] = c; box[2 * h] = box_of(c); continue; }              // a leaf takes one slot of its half
+            axes |= out.nodes[(size_t)c].axis << (8 * (h + 1));
+            const int32_t gk[2] = {out.nodes[(size_t)c].left, out.nodes[(size_t)c].right};
+            for (int k = 0; k < 2; ++k) { box[2 * h + k] = box_of(gk[k]); child[2 * h + k] = gk[k] < 0 ? gk[k] : widen(gk[k]); }
+        }
+        double* w = &out.wide[at];
+        for (int c = 0; c < 4; ++c) for (int a = 0; a < 3; ++a) { w[6 * c + a] = box[c].lo[a]; w[6 * c + 3 + a] = box[c].hi[a]; }
+        std::memcpy(w + 24, child, sizeof child);
+        std::memcpy(w + 26, &axes, sizeof axes);
+        return (int32_t)(at / ftd::kWideNodeDoubles);
     }
     int32_t bvh_for_leaf(const std::vector<Tri3>& ts, uint32_t first_global) {
         if (ts.size() < 8) return INT32_MIN;
@@ -588,12 +618,15 @@ int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatSce
     if (b.failed) return FT_ERR_BUILD;
     mesh.root = root; mesh.n_source_tris = (uint32_t)n_tris; mesh.max_depth = b.max_depth;
     mesh.bvh_root = INT32_MIN;
+    int32_t wide_root = INT32_MIN;
     if (root < 0) {                                                             // top-level Leaf: add the exact BVH for closest / any-hit queries
         const size_t n0 = out.nodes.size(), l0 = out.bsp_leaves.size(), t0 = out.tris.size() / 9;
         mesh.bvh_root = b.bvh_for_leaf(ts, out.bsp_leaves[(size_t)~root].first_tri);
+        wide_root = mesh.bvh_root >= 0 ? b.widen(mesh.bvh_root) : INT32_MIN;
         out.bvh_nodes += (int64_t)(out.nodes.size() - n0); out.bvh_leaves += (int64_t)(out.bsp_leaves.size() - l0); out.bvh_tris += (int64_t)(out.tris.size() / 9 - t0);
         if (mesh.bvh_root >= 0 && (int32_t)b.bvh_depth + 1 > out.stack_capacity) out.stack_capacity = (int32_t)b.bvh_depth + 1;
     }
+    out.mesh_wide.push_back(wide_root);
     return FT_OK;
 }
 
