@@ -1619,24 +1619,28 @@ __global__ __launch_bounds__(kBlock, 2) void k_tail(TailArgs) {
     if (lane_id() == 0 && ref_wave != 0.0) mine->ref_equiv += ref_wave;
 }
 
-__global__ __launch_bounds__(kBlock) void k_reduce_stats(RenderCounters* slots, uint32_t n_slots) {   // one block; slot 0 receives the totals
-    __shared__ RenderCounters part[kBlock];
+__global__ __launch_bounds__(64) void k_reduce_stats(RenderCounters* slots, uint32_t n_slots) {   // one wave per 64 slots; slot 0 receives the totals
+    const uint32_t k = 1 + blockIdx.x * 64 + threadIdx.x;
     RenderCounters s{0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0};
-    for (uint32_t k = 1 + threadIdx.x; k <= n_slots; k += kBlock) {
-        s.rays_shadow += slots[k].rays_shadow; s.rays_reflect += slots[k].rays_reflect; s.hits_primary += slots[k].hits_primary;
-        s.tail_in += slots[k].tail_in; s.tail_rays += slots[k].tail_rays; s.tail_hits += slots[k].tail_hits; s.pixels_culled += slots[k].pixels_culled;
-        s.csg_overflow += slots[k].csg_overflow; s.ref_equiv += slots[k].ref_equiv; s.hits_total += slots[k].hits_total;
+    if (k <= n_slots) s = slots[k];
+    for (int off = 32; off > 0; off >>= 1) {                       // wave reduction, then one lane adds to the total
+        s.rays_shadow += __shfl_down(s.rays_shadow, off); s.rays_reflect += __shfl_down(s.rays_reflect, off); s.hits_primary += __shfl_down(s.hits_primary, off);
+        s.csg_overflow += __shfl_down(s.csg_overflow, off); s.ref_equiv += __shfl_down(s.ref_equiv, off); s.hits_total += __shfl_down(s.hits_total, off);
+        s.tail_in += __shfl_down(s.tail_in, off); s.tail_rays += __shfl_down(s.tail_rays, off); s.tail_hits += __shfl_down(s.tail_hits, off);
+        s.pixels_culled += __shfl_down(s.pixels_culled, off);
     }
-    part[threadIdx.x] = s;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        RenderCounters t = slots[0];                              // debug kernels add to slot 0 directly
-        for (int k = 0; k < kBlock; ++k) {
-            t.rays_shadow += part[k].rays_shadow; t.rays_reflect += part[k].rays_reflect; t.hits_primary += part[k].hits_primary;
-            t.tail_in += part[k].tail_in; t.tail_rays += part[k].tail_rays; t.tail_hits += part[k].tail_hits; t.pixels_culled += part[k].pixels_culled;
-            t.csg_overflow += part[k].csg_overflow; t.ref_equiv += part[k].ref_equiv; t.hits_total += part[k].hits_total;
-        }
-        slots[0] = t;
+        RenderCounters* t = slots;
+        if (s.rays_shadow) atomicAdd(&t->rays_shadow, s.rays_shadow);
+        if (s.rays_reflect) atomicAdd(&t->rays_reflect, s.rays_reflect);
+        if (s.hits_primary) atomicAdd(&t->hits_primary, s.hits_primary);
+        if (s.csg_overflow) atomicAdd(&t->csg_overflow, s.csg_overflow);
+        if (s.ref_equiv != 0.0) atomicAdd(&t->ref_equiv, s.ref_equiv);
+        if (s.hits_total) atomicAdd(&t->hits_total, s.hits_total);
+        if (s.tail_in) atomicAdd(&t->tail_in, s.tail_in);
+        if (s.tail_rays) atomicAdd(&t->tail_rays, s.tail_rays);
+        if (s.tail_hits) atomicAdd(&t->tail_hits, s.tail_hits);
+        if (s.pixels_culled) atomicAdd(&t->pixels_culled, s.pixels_culled);
     }
 }
 
@@ -1776,7 +1780,7 @@ void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touc
     hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, w, h, out_index, out_rgb);
 }
 void launch_reduce_stats(const Launch& L, RenderCounters* slots, uint32_t n_slots) {
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(kBlock), 0, L.stream, slots, n_slots);
+    hipLaunchKernelGGL(k_reduce_stats, dim3((n_slots + 63) / 64), dim3(64), 0, L.stream, slots, n_slots);
 }
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n, int32_t* hit, double* t,
                           double* p, double* nrm, double* colour, RenderCounters* rc) {

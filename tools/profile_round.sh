@@ -1,0 +1,17 @@
+#!/bin/bash
+# All profiles of the default bench command for one round (GPU box): kernel stats, HBM traffic (two PMC passes), VALU occupancy
+# (two PMC passes).  usage: tools/profile_round.sh <tag>   -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
+set -e
+tag=$1
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B > gpurun_out/${tag}_bench_under_stats.json 2>/dev/null
+cp $(ls gpurun_out/${tag}_stats/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats.csv
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d gpurun_out/${tag}_write -- $B > /dev/null 2>&1
+python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write --pixels 2073600 --spp 16 > gpurun_out/${tag}_pmc_traffic.json
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 -d gpurun_out/${tag}_va -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/${tag}_vb -- $B > /dev/null 2>&1
+python3 tools/pmc_valu.py gpurun_out/${tag}_va gpurun_out/${tag}_vb > gpurun_out/${tag}_pmc_valu.json
+find gpurun_out/${tag}_* -name "*.csv" -size +1M -delete
+cat gpurun_out/${tag}_kernel_stats.csv | cut -c1-150; cat gpurun_out/${tag}_pmc_valu.json
