@@ -198,8 +198,16 @@ def main():
             if t:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command
                 out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"])
                 out["roofline"]["traffic_source"] = os.path.relpath(traffic_file, ROOT)
+        valu_file = os.path.join(ROOT, "profiles", f"pmc_valu_{args.scene}.json")
+        if os.path.exists(valu_file) and world == 1 and not args.res and not args.spp:
+            with open(valu_file) as f:
+                v = json.load(f).get("k_" + dom)
+            if v:   # informational: the path is FP64-VALU / scalar / latency bound, not HBM bound (tools/pmc_valu.py, same command)
+                out["roofline"]["valu"] = {"busy_frac": v["valu_busy_frac"], "fp64_tflops_upper": v["fp64_tflops_upper"], "fp64_peak_tflops": 78.6,
+                                           "salu_per_valu_inst": round(v["salu_insts"] / max(1.0, v["valu_insts"]), 3), "source": os.path.relpath(valu_file, ROOT)}
         out["rays_per_frame"] = {"traced_rank0": int(rays_rank), "traced_all_ranks": int(rays_total / steps),
-                                 "reference_equivalent_rank0": st["rays_reference_equivalent"]}
+                                 "reference_equivalent_rank0": st["rays_reference_equivalent"],
+                                 "primary_resolved_per_64_pixel_block_rank0": int(st["rays_primary_culled"])}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, res_h, res_v, spp, jitter, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)

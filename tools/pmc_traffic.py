@@ -37,15 +37,18 @@ def main():
     ap.add_argument("--pixels", type=int, required=True)
     ap.add_argument("--spp", type=int, required=True)
     ap.add_argument("--read-scale", type=float, default=2.0, help="FETCH_SIZE correction for this path's coalesced 8 B/lane reads")
+    ap.add_argument("--active-pixels", type=int, default=0, help="pixels k_classify kept (ft_stats: (rays_primary - rays_primary_culled) / spp); they also cost 8 B of list each")
+    ap.add_argument("--frames", type=int, default=7, help="frames rendered by the profiled command (steps + warmup)")
     args = ap.parse_args()
     fetch, write = load(args.fetch_dir, "FETCH_SIZE"), load(args.write_dir, "WRITE_SIZE")
-    n_blend = len(fetch.get("k_blend", [])) or 1
-    known_write = 24.0 * args.pixels / n_blend                     # per k_blend launch
-    blend_write = sum(write["k_blend"]) / max(1, len(write["k_blend"]))
+    # Every pixel of a frame is written exactly once, 24 B, by k_classify (blocks that see nothing) or k_blend (the rest), and every
+    # active pixel costs 8 B of list: the known byte count that checks WRITE_SIZE in every run.
+    known_write = (24.0 * args.pixels + 8.0 * args.active_pixels) * args.frames
+    out_write = sum(write.get("k_blend", [])) + sum(write.get("k_classify", []))
     read_scale = args.read_scale
     out = {"calibration": {"read_scale": read_scale, "read_scale_source": "k_blend full-accumulator passes r01_d / r01_j: 1.979, 1.9998",
-                           "known_write_bytes_per_launch_k_blend": known_write, "WRITE_SIZE_bytes_per_launch_k_blend": blend_write,
-                           "write_ratio": blend_write / known_write}}
+                           "known_output_bytes_all_frames": known_write, "WRITE_SIZE_k_blend_plus_k_classify_all_frames": out_write,
+                           "write_ratio": out_write / known_write}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
