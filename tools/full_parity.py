@@ -15,7 +15,7 @@ from oracle import ft_oracle_py as O  # noqa: E402
 
 CONFIGS = [  # BASELINE.json configs 1-4 (+ the as-written soft-light night-house); config 5 is the 8-GPU tiling of bunny
     ("sample-det", 256, 256, 1), ("hollow-sphere", 1920, 1080, 1), ("bunny", 1920, 1080, 4), ("bunny", 1920, 1080, 16),
-    ("bunny-bsp12", 1920, 1080, 4), ("night-house-det", 1920, 1080, 16), ("night-house", 1920, 1080, 16)]
+    ("bunny-bsp12", 1920, 1080, 4), ("night-house-det", 1920, 1080, 16), ("night-house", 1920, 1080, 16), ("moon", 400, 400, 1)]
 if len(sys.argv) > 1:
     CONFIGS = [c for c in CONFIGS if c[0] in sys.argv[1:]]
 ctx = ft.Context(0)
