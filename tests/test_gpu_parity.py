@@ -489,3 +489,76 @@ def test_pixel_block_classification_changes_no_pixel(hip, name):
         assert s1["rays_primary_culled"] > 0 and st1["rays_primary_culled"] > 0
     for key in ("rays_primary", "rays_shadow", "rays_reflect", "rays_traced", "hits_primary", "hits_total", "rays_reference_equivalent"):
         assert s0[key] == s1[key] and st0[key] == st1[key], key
+
+
+def _grid_of_pairs(b, nx, ny, reflect=0.4):
+    """nx * ny CSG pairs (cube - sphere / cube & sphere alternating, as Scenes/hollow-sphere.scene:7-33 does) inside a shell."""
+    b.clear()
+    items = [b.material(b.subtract(b.scale(30, b.primitive(ft.SPHERE)), b.scale(29, b.primitive(ft.SPHERE))), colour=(0.4, 0.4, 0.4))]
+    for j in range(ny):
+        for i in range(nx):
+            op = b.subtract if (i + j) % 2 == 0 else b.intersect
+            node = op(b.primitive(ft.CUBE), b.scale(0.65, b.primitive(ft.SPHERE)))
+            items.append(b.material(b.translate((1.3 * (i - nx / 2), 1.3 * (j - ny / 2), 0.0), node), colour=(1, (i % 3) / 2, (j % 3) / 2), reflectance=reflect, shineyness=10))
+    b.set_objects(b.group(items))
+    b.add_positional((0, 0, -8), (1, 0.01, 0.02), (1, 1, 1))
+    b.commit()
+
+
+def test_axis_aligned_rays_take_the_generic_csg_route(hip):
+    """Rays parallel to cube faces get hits at the ray origin from Plane.fs:13-16: an operand then has more than two hits and
+    OP_CSG_PAIR must fall back to the generic sequence, coherent and incoherent alike."""
+    orc = O.Oracle()
+    for b in (orc, hip):
+        _grid_of_pairs(b, 3, 3)
+    rng = np.random.default_rng(77)
+    n = 6000
+    o = rng.uniform(-2.5, 2.5, size=(n, 3))
+    o[: n // 2] = np.round(o[: n // 2] * 4) / 4                  # many origins exactly on face planes (x, y, z = +-0.5 + k * 1.3 are not; 0.25 steps inside cubes are)
+    axes = np.eye(3)[rng.integers(0, 3, size=n)] * rng.choice([-1.0, 1.0], size=(n, 1)) * rng.uniform(0.5, 2.0, size=(n, 1))
+    d = axes.copy()
+    d[n // 2:] += rng.normal(scale=1e-9, size=(n - n // 2, 3))    # and nearly parallel ones, on both sides of the 1e-7 rule
+    H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="axis-aligned rays through CSG pairs")
+    md = np.abs(rng.normal(size=n)) * 5.0
+    assert np.array_equal(hip.blocked(o, d, md), orc.blocked(o, d, md))
+
+
+def test_more_items_than_the_item_mask_covers(hip):
+    """150 top-level items: the wave-level item masks cover 128, the rest runs behind its own OP_CULL; frame, ray counts and
+    explicit incoherent rays must match the oracle."""
+    orc = O.Oracle()
+    for b in (orc, hip):
+        _grid_of_pairs(b, 15, 10, reflect=0.3)
+    assert hip.scene_info()["leaves"] == 2 + 2 * 150
+    o, d = H.random_rays(20000, seed=5, origin_scale=6.0, toward=(0, 0, 0), spread=6.0)
+    H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="150 CSG pairs")
+    cam = ft.make_camera((6, 5, -14), (0, 0, 0), (0, 1, 0), H.deg(60.0))
+    jit = ft.jitter_pattern(2)
+    want, ost = orc.render(cam, 192, 128, 2, jit)
+    got, st = hip.render(cam, 192, 128, 2, jit)
+    assert H.assert_frames_match(got, want, what="150 CSG pairs") < 1e-6
+    assert st["rays_reference_equivalent"] == ost["rays_traced"]
+
+
+def test_coincident_items_resolve_ties_in_scene_order(hip):
+    """Two identical spheres with different materials: every hit is a tie, and the reference's stable sort keeps the first
+    object of the scene (Scene.fs:112-116) - whatever route the wavefront takes to the items."""
+    orc = O.Oracle()
+    for b in (orc, hip):
+        b.clear()
+        objs = [b.material(b.primitive(ft.SPHERE), colour=c) for c in ((1, 0, 0), (0, 1, 0), (0, 0, 1))]
+        objs += [b.material(b.translate((2.5 * k, 0, 0), b.primitive(ft.CUBE)), colour=(1, 1, 1)) for k in (-1, 1)]
+        b.set_objects(b.group(objs))
+        b.add_directional((0, -1, 1), (1, 1, 1))
+        b.commit()
+    o, d = H.random_rays(5000, seed=9, origin_scale=3.0)
+    got, want = hip.closest(o, d), orc.closest(o, d)
+    H.assert_hits_match(got, want, what="coincident spheres")
+    hit = want[0].astype(bool)
+    on_sphere = hit & (np.abs(np.linalg.norm(want[2], axis=1) - 1.0) < 1e-9)
+    assert on_sphere.sum() > 100 and (got[4][on_sphere] == (1.0, 0.0, 0.0)).all()
+    cam = ft.make_camera((0, 1, -6), (0, 0, 0), (0, 1, 0), H.deg(50.0))
+    jit = ft.jitter_pattern(1)
+    want_f, _ = orc.render(cam, 128, 96, 1, jit)
+    got_f, _ = hip.render(cam, 128, 96, 1, jit)
+    assert H.assert_frames_match(got_f, want_f, what="coincident spheres") < 1e-9
