@@ -51,6 +51,8 @@ struct ft_context {
     size_t events_used = 0;
     // pixel list of the last render, cached across calls with the same resolution and tiles
     std::vector<uint32_t> pixels;
+    std::vector<double> jitter_on_device;   // what d_jitter holds
+    ftk::RenderCounters* h_rc = nullptr;    // pinned landing place of the per-render statistics
     std::vector<ft_rect> pixel_rects;
     bool pixels_whole = false, pixels_corner = false;
     DeviceBuf d_out_index;
@@ -201,6 +203,7 @@ void ft_destroy(ft_context* c) {
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
+        if (c->h_rc) { (void)hipHostFree(c->h_rc); c->h_rc = nullptr; }
         for (auto e : c->events) (void)hipEventDestroy(e);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
@@ -539,7 +542,10 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     std::vector<double> jit;
     if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
     else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
-    if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
+    if (jit != c->jitter_on_device) {                              // frames usually reuse the pattern: skip the staged host-to-device copy
+        if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
+        c->jitter_on_device = jit;
+    }
     FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 1), c->stream));
 
     // k_classify applies to pinhole cameras over whole 64-pixel blocks and scenes in which every top-level item is bounded
@@ -615,10 +621,11 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, ftk::kStatSlots); });
     ev1 = boundary;
     FT_HIP(c, hipGetLastError());
+    if (!c->h_rc) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rc), sizeof(ftk::RenderCounters), hipHostMallocDefault));
+    FT_HIP(c, hipMemcpyAsync(c->h_rc, c->d_rc.p, sizeof(ftk::RenderCounters), hipMemcpyDeviceToHost, c->stream));   // rides the same wait
     FT_HIP(c, hipStreamSynchronize(c->stream));
 
-    ftk::RenderCounters hrc{};
-    FT_HIP(c, hipMemcpy(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost));
+    const ftk::RenderCounters hrc = *c->h_rc;
     c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v;
     if (out_rgb) { int32_t frc = fetch_single(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
     for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }

@@ -1436,7 +1436,7 @@ struct ClassifyArgs {
     DevScene S; Primary gen;                                        // gen.pixel_ids / pix_base / n_pix: the chunk's full pixel list
     uint32_t* active_ids; uint32_t* active_pos; PixCount* counts; double* out; RenderCounters* rc; int32_t whole;
 };
-constexpr uint32_t kClassifyRun = 8;                                // consecutive blocks per wave: one list reservation for all of them
+constexpr uint32_t kClassifyRun = 4;                                // consecutive blocks per wave: one list reservation for all of them
 
 __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
     const FT_CONST ClassifyArgs* K = kernel_args<ClassifyArgs>();
