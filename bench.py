@@ -113,7 +113,7 @@ def main():
     t0 = time.perf_counter()
     rays = 0
     kernel_ms = trace_ms = 0.0
-    k_times = {"clear": 0.0, "closest": 0.0, "shade": 0.0, "blend": 0.0}
+    k_times = {"other": 0.0, "closest": 0.0, "shade": 0.0, "blend": 0.0}   # "other": memsets, k_classify, k_blend, statistics (events bracket k_closest / k_shade only)
     k_launch = dict.fromkeys(k_times, 0)
     st = None
     for _ in range(args.steps):

@@ -226,7 +226,7 @@ class Context(SceneBuilder):
         ms = np.zeros(4)
         n = np.zeros(4, dtype=np.int32)
         self._check(self._lib.ft_get_kernel_times(self._ctx, _capi.dptr(ms), n.ctypes.data_as(_capi.c_int32_p)))
-        names = ["clear", "closest", "shade", "blend"]
+        names = ["other", "closest", "shade", "blend"]   # "other": memsets, k_classify, statistics (and k_blend unless "timing" = 2)
         return {k: {"ms": float(ms[i]), "launches": int(n[i])} for i, k in enumerate(names)}
 
     def closest(self, origins, dirs):

@@ -38,6 +38,7 @@ struct ft_context {
     bool committed = false;
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
+    int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
     int64_t tail_rays = 65536;       // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
@@ -216,6 +217,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!c || !key) return FT_ERR_INVALID;
     if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; for (ft_context* p : c->peers) p->chunk_samples = value; return FT_OK; }
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
+    if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
@@ -576,16 +578,23 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     c->events_used = 0;
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
-    // One event per stage boundary (the end of a stage is the start of the next): half the markers of a pair per stage.
+    // HIP events between stages.  An event between two dependent kernels costs about 6 us of stream time (measured: 0.2 us
+    // between k_classify and k_classify_finish, which have none between them), so by default ("timing" = 1) only the two
+    // kernels that matter, k_closest and k_shade, are bracketed; 2 brackets every stage, 0 only the frame.
     hipEvent_t ev0 = next_event(c), ev1 = nullptr;
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     hipEvent_t boundary = ev0;
+    bool boundary_fresh = true;                                    // `boundary` was recorded right before the next launch
+    const int timing = c->timing;
     auto timed = [&](int kind, auto&& fn) {
+        const bool bracket = timing >= 2 || (timing == 1 && (kind == 1 || kind == 2));
+        if (bracket && !boundary_fresh) { boundary = next_event(c); if (boundary) (void)hipEventRecord(boundary, c->stream); }
         fn();
+        if (!bracket) { boundary_fresh = false; return; }
         hipEvent_t b = next_event(c);
         if (b) (void)hipEventRecord(b, c->stream);
         if (boundary && b) spans.push_back({boundary, b, kind});
-        boundary = b;
+        boundary = b; boundary_fresh = true;
     };
     int n_chunks = 0, n_launches = 0;
     for (const Job& job : jobs) {
@@ -619,7 +628,8 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         ++n_launches;
     }
     timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, ftk::kStatSlots); });
-    ev1 = boundary;
+    if (boundary_fresh) ev1 = boundary;
+    else { ev1 = next_event(c); if (ev1) (void)hipEventRecord(ev1, c->stream); }
     FT_HIP(c, hipGetLastError());
     if (!c->h_rc) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rc), sizeof(ftk::RenderCounters), hipHostMallocDefault));
     FT_HIP(c, hipMemcpyAsync(c->h_rc, c->d_rc.p, sizeof(ftk::RenderCounters), hipMemcpyDeviceToHost, c->stream));   // rides the same wait
@@ -630,6 +640,10 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     if (out_rgb) { int32_t frc = fetch_single(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
     for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
     for (auto& s : spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; } }
+    if (timing < 2) {                                              // index 0 = everything that was not bracketed (memsets, k_classify, k_blend, statistics)
+        float total = 0; if (ev0 && ev1) (void)hipEventElapsedTime(&total, ev0, ev1);
+        c->k_ms[0] = std::max(0.0, (double)total - c->k_ms[1] - c->k_ms[2]); c->k_ms[3] = 0.0;
+    }
     if (stats) {
         float ms = 0;
         if (ev0 && ev1) (void)hipEventElapsedTime(&ms, ev0, ev1);

@@ -136,7 +136,8 @@ int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out
 void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);
 /* Tunables: "chunk_samples" (samples in flight per launch), "csg_mesh_capacity" (hit-list entries a mesh may add under
- * CSG), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
+ * CSG), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around every
+ * k_closest / k_shade launch, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
  * cannot reach any object are finished before any ray is generated), "tail_rays" (a bounce starting with fewer rays is finished by the tail
  * kernel in one launch; 0 = never; default 65536), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits).  Scene-affecting options need a new ft_scene_commit. */
@@ -207,8 +208,8 @@ int32_t ft_create_host_only(ft_context** out);
 int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[8]);
 int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9],
                        double above[18], int32_t* n_above, double below[18], int32_t* n_below);
-/* HIP-event time per stage over the last ft_render: index 0 accumulator clear (primary rays are generated inside bounce 0),
- * 1 closest, 2 shade (and the tail kernel), 3 blend. */
+/* HIP-event time per stage over the last ft_render: index 1 closest, 2 shade (and the tail kernel); with "timing" = 2 also
+ * 3 blend and 0 the rest (memsets, classification, statistics); otherwise 0 = everything but closest and shade, 3 = 0. */
 int32_t ft_get_kernel_times(ft_context* ctx, double ms[4], int32_t launches[4]);
 
 /* Image.write's toByte (Image.fs:36): clamp to [0,1], *255, truncate; alpha = 255. */
