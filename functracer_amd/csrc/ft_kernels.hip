@@ -1,9 +1,11 @@
 // ft_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the FuncTracer render loop.
 //
 // Pipeline per chunk of samples (DESIGN.md §"Kernels"):
+//   k_classify  which 64-pixel blocks can see anything; the rest are finished on the spot (Colour.Zero)
 //   (primary rays are generated inside bounce 0 of the two kernels below: Image.fs:83-89, 100-110)
 //   k_closest   closest hit         Scene.fs:112-118 over the flattened Scene.intersect (Scene.fs:67-104)
 //   k_shade     Phong + shadow rays + reflection spawn   Shading.fs:24-139
+//   k_tail      the same two, path by path, for the few rays of the late bounces (one launch instead of two per bounce)
 //   k_blend     per-pixel mean      Image.fs:112-116
 // k_closest / k_shade run once per bounce; reflection rays and hit records live in wavefront buffers in
 // HBM, rays that terminate are dropped by wave-ballot / prefix-sum compaction, so every lane of the next stage
@@ -16,7 +18,9 @@
 //   * per-lane CSG hit lists and BSP node stacks live in LDS, laid out [entry][lane] so that a
 //     wave access is always bank-conflict free whatever entry each lane touches;
 //   * waves are independent: no __syncthreads in any tracing kernel;
-//   * coherent wavefronts (one 8x8 pixel block) walk mesh trees as a packet with a wave-uniform stack.
+//   * coherent wavefronts (one 8x8 pixel block) walk mesh trees as a packet with a wave-uniform stack, and bound their
+//     rays by a cone that is tested against the bounding spheres of all top-level items at once (one lane per item);
+//   * launch arguments are read from the kernarg segment where they are used (scalar loads), not held in SGPRs.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
