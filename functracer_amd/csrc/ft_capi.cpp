@@ -38,6 +38,7 @@ struct ft_context {
     bool committed = false;
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
+    bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
     int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
     int64_t tail_rays = 65536;       // a bounce that starts with fewer rays is finished by k_tail (0 = never)
@@ -217,6 +218,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!c || !key) return FT_ERR_INVALID;
     if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; for (ft_context* p : c->peers) p->chunk_samples = value; return FT_OK; }
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
+    if (!std::strcmp(key, "coherent_waves")) { c->coherent_waves = value != 0; c->dev_scene.coherent_waves = value != 0 ? 1 : 0; for (ft_context* p : c->peers) { p->coherent_waves = value != 0; p->dev_scene.coherent_waves = c->dev_scene.coherent_waves; } return FT_OK; }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
@@ -370,6 +372,7 @@ static int32_t upload_scene(ft_context* c) {
     S.cull_items = c->d_cull_items.as<float>(); S.cull_rows = c->d_cull_rows.as<double>();
     S.wide = c->d_wide.as<double>(); S.mesh_wide = c->d_mesh_wide.as<int32_t>();
     S.item_pc = c->d_item_pc.as<uint32_t>();
+    S.coherent_waves = c->coherent_waves ? 1 : 0;
     S.n_items = (int32_t)f.item_pc.size() - 1; S.n_cull_rows = f.cull_bundle ? (int32_t)(f.cull_rows.size() / 3) : -1;
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;

@@ -35,7 +35,7 @@ struct DevScene {
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
     int32_t shadow_rays_per_hit;   // sum over lights of the shadow rays the reference casts per hit
     int32_t n_items, n_cull_rows;  // n_cull_rows < 0: pre-test disabled
-    int32_t pad;   // sum over lights of the shadow rays the reference casts per hit
+    int32_t coherent_waves;        // 1 (default): bounce-0 wavefronts use the bundle paths (cone cull, packet traversal); 0: every wave is treated as incoherent (diagnostic)   // sum over lights of the shadow rays the reference casts per hit
 };
 
 // Ray wavefront buffer, struct-of-arrays so a wave's 64 records are 512 contiguous bytes per field.

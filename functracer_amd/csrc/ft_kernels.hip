@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
             }
         }
         bool overflow;
-        trace<false, MESH>(S, r, q, lds, overflow, bounce == 0);   // primary rays of one pixel block walk meshes as a packet
+        trace<false, MESH>(S, r, q, lds, overflow, bounce == 0 && K->S.coherent_waves != 0);   // primary rays of one pixel block walk meshes as a packet
         const bool hit = q.active && q.id0 != ID_MISS;
         {
             const FT_CONST ClosestArgs* Ke = fresh(K);
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
             if (SOFT) sample = sample_id(&Kb->gen, slot);
         }
         unsigned long long vis_lo, vis_hi;                         // byte l = occluded shadow samples of light l
-        light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, bounce, bounce == 0, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
+        light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, bounce, bounce == 0 && K->S.coherent_waves != 0, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
         // ---------------- pass 2: the shaders (Shading.fs:50-107) with everything reloaded ------------------
         Ray r{0, 0, 0, 0, 0, 0};
         double w = 0.0; uint32_t slot = 0;
@@ -1423,7 +1423,8 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
     // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts its shadow rays
     // and each reflective hit L reflection rays (Shading.fs:109-139).
     if (lane_id() == 0 && (n_hit_wave || n_refl_wave)) {
-        const double mult = pow((double)n_lights, (double)bounce);
+        double mult = 1.0;                                          // L^bounce by multiplication: exact, pow is not for L = 3
+        for (int k = 0; k < bounce; ++k) mult *= (double)n_lights;
         mine->ref_equiv += mult * ((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
     }
 }
@@ -1568,7 +1569,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_tail(TailArgs) {
             r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i];
         }
         n_in_wave += (unsigned long long)__popcll(__ballot(alive));
-        double mult = pow((double)n_lights, (double)k0);          // copies of this ray in the F# recursion (Shading.fs:109-139)
+        double mult = 1.0;                                        // copies of this ray in the F# recursion (Shading.fs:109-139): L^k0, exactly
+        for (int k = 0; k < k0; ++k) mult *= (double)n_lights;
         for (int depth = k0; __any(alive); ++depth, mult *= (double)n_lights) {
             // ---- closest hit (k_closest)
             Query<false> q;

@@ -71,7 +71,7 @@ class Oracle(_capi.SceneBuilder):
         except Exception:
             pass
 
-    def render(self, camera, res_h, res_v, spp, jitter, max_depth=8, seed=0, tiles=None, threads=0, out=None):
+    def render(self, camera, res_h, res_v, spp, jitter, max_depth=8, seed=20260104, tiles=None, threads=0, out=None):   # seed: functracer_amd.DEFAULT_SEED, so both sides draw the same streams by default
         jitter = np.zeros((1, 2)) if spp == 0 else _capi.as_f64(jitter, (spp, 2))   # spp == 0: `samples corner` (Image.fs:125-150)
         if out is None:
             out = np.zeros((res_v, res_h, 3))
