@@ -61,8 +61,22 @@ class SceneRecipe:
             node = self._emit("hue_shift", 0.0, node)
         return node
 
+    def _mesh(self):
+        """A bumpy closed-ish fan of triangles around the origin: enough of them (>= 8) for the device-side BVH at depth 0."""
+        r = self.rng
+        n = int(r.integers(10, 40))
+        ring = [(np.cos(a) * (0.7 + 0.3 * r.random()), np.sin(a) * (0.7 + 0.3 * r.random()), 0.3 * r.normal()) for a in np.linspace(0, 2 * np.pi, n, endpoint=False)]
+        top, bottom = (0.05 * r.normal(), 0.05 * r.normal(), 0.8), (0.05 * r.normal(), 0.05 * r.normal(), -0.8)
+        tris = []
+        for k in range(n):
+            a, b = ring[k], ring[(k + 1) % n]
+            tris.append([a, b, top]); tris.append([b, a, bottom])
+        return self._emit("bsp_mesh", int(r.choice([0, 0, 2, 4])), np.array(tris, dtype=np.float64).reshape(-1, 9).tolist())
+
     def _solid(self, depth):
         r = self.rng
+        if r.random() < (0.15 if depth == 0 else 0.04):
+            return self._xf(self._mesh(), 0.4)
         if depth >= 3 or r.random() < 0.55:
             return self._xf(self._emit("primitive", int(r.choice(PRIMS))), 0.4)
         a, b = self._solid(depth + 1), self._solid(depth + 1)
@@ -97,8 +111,16 @@ class SceneRecipe:
         b.commit()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(32))
 def test_random_scene_matches_oracle(hip, seed):
+    hip.set_option("csg_mesh_capacity", 8)                        # hit-list entries a mesh may add under CSG: these fans are crossed at most 4 times
+    try:
+        _check_random_scene(hip, seed)
+    finally:
+        hip.set_option("csg_mesh_capacity", 32)                   # (scene-affecting option: the next test commits its own scene)
+
+
+def _check_random_scene(hip, seed):
     recipe = SceneRecipe(1000 + seed)
     orc = O.Oracle()
     recipe.build(orc)
