@@ -44,7 +44,7 @@ struct ft_context {
     int64_t tail_rays = 65536;       // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_active_ids, d_active_pos, d_wide, d_mesh_wide;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_active_ids, d_active_pos, d_wide, d_mesh_wide, d_coarse;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_touched, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
@@ -201,7 +201,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_active_ids, &c->d_active_pos, &c->d_wide, &c->d_mesh_wide, &c->d_out_index,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_active_ids, &c->d_active_pos, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -360,6 +360,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_item_pc, f.item_pc)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_wide, f.wide)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_mesh_wide, f.mesh_wide)) != FT_OK) return rc;
+    if ((rc = upload(c, c->d_coarse, f.coarse_boxes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 1))) != FT_OK) return rc;
@@ -369,6 +370,7 @@ static int32_t upload_scene(ft_context* c) {
     S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>(); S.textures = c->d_textures.as<ftd::Texture>();
     S.program = c->d_program.as<uint32_t>(); S.meshes = c->d_meshes.as<ftd::Mesh>();
     S.nodes = c->d_nodes.as<ftd::BspNode>(); S.bsp_leaves = c->d_bleaves.as<ftd::BspLeaf>(); S.tris = c->d_tris.as<double>(); S.culls = c->d_culls.as<double>(); S.tri_orig = c->d_tri_orig.as<uint32_t>(); S.tex_pixels = c->d_tex_pixels.as<uint8_t>();
+    S.coarse_boxes = c->d_coarse.as<float>();
     S.cull_items = c->d_cull_items.as<float>(); S.cull_rows = c->d_cull_rows.as<double>();
     S.wide = c->d_wide.as<double>(); S.mesh_wide = c->d_mesh_wide.as<int32_t>();
     S.item_pc = c->d_item_pc.as<uint32_t>();

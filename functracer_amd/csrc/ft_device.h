@@ -29,7 +29,8 @@ struct DevScene {
     const double* wide;            // 28 doubles per 4-wide BVH node (ft_flat.h)
     const int32_t* mesh_wide;      // per mesh: root of its 4-wide BVH or INT32_MIN
     const uint8_t* tex_pixels;     // Rgb24 rows of the image textures (ftd::Texture::pixel_base indexes into it)
-    const float* cull_items;       // 8 floats per top-level item (centre, radius, row mask): wave-level pre-test of the item culls
+    const float* cull_items;       // 8 floats per top-level item (centre, radius, row mask; bare meshes: + first coarse box, count, leaf)
+    const float* coarse_boxes;     // 6 floats per box: model-space boxes that cover a mesh (k_classify)
     const uint32_t* item_pc;       // n_items + 1 program counters: where each top-level item starts (last: the OP_END word)
     const double* cull_rows;       // 3 per distinct parallel-sensitive direction
     int32_t n_leaves, n_lights, csg_cap, stack_cap;

@@ -88,6 +88,7 @@ struct Scene {
     cip mesh_wide;    // 1 per mesh
     const uint8_t* tex_pixels;   // per-lane byte gathers: ordinary global loads
     const float* cull_items;     // lane k reads record k: ordinary global loads
+    const float* coarse_boxes;   // lane k reads box k
     cdp cull_rows;
     cup item_pc;
     int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows;
@@ -101,7 +102,7 @@ template <class DS> FT_DEV Scene scene_view(const DS& g) {
     s.program = to_const_as(g.program); s.meshes = to_const_as(reinterpret_cast<const int32_t*>(g.meshes));
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig); s.wide = to_const_as(g.wide); s.mesh_wide = to_const_as(g.mesh_wide);
-    s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
+    s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.coarse_boxes = g.coarse_boxes; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
     s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
     return s;
 }
@@ -1500,7 +1501,59 @@ __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
                 }
                 const Cone B{ax, ay, az, (float)g->cam.o[0], (float)g->cam.o[1], (float)g->cam.o[2], cos_t, sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f,
                              1e-5f * (1.0f + fabsf((float)g->cam.o[0]) + fabsf((float)g->cam.o[1]) + fabsf((float)g->cam.o[2])), par_rows};
-                const ItemMask M = items_in_cone(S, B);
+                ItemMask M = items_in_cone(S, B);
+                // A bare mesh that survived its bounding sphere is tested once more, against the <= 64 boxes that hold all its
+                // triangles: the pyramid through the block's outermost pixel corners, taken into the mesh's model space, must reach
+                // one of them (lane k: box k; a box wholly behind one side plane of the pyramid is out of reach).
+                for (int half = 0; half < 2; ++half) {
+                    unsigned long long todo = half == 0 ? M.lo : M.hi;
+                    while (todo) {
+                        const int bit = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
+                        const uint32_t item = (uint32_t)(64 * half + bit);
+                        const FT_CONST float* I = to_const_as(S.cull_items) + 8u * item;
+                        const uint32_t n_box = __float_as_uint(I[6]);
+                        if (n_box == 0u) continue;
+                        const uint32_t first_box = __float_as_uint(I[5]), leaf = __float_as_uint(I[7]);
+                        // pixel bounds of the block (+- one pixel of jitter), as image-plane coordinates
+                        const float fpx = (float)px, fpy = (float)py;
+                        const float x0 = wave_min(fpx), x1 = -wave_min(-fpx), y0 = wave_min(fpy), y1 = -wave_min(-fpy);
+                        const double jx0 = g->cam.tlx + ((double)x0 - 1.001) * g->cam.pw, jx1 = g->cam.tlx + ((double)x1 + 1.001) * g->cam.pw;
+                        const double jy0 = g->cam.tly - ((double)y1 + 1.001) * g->cam.ph, jy1 = g->cam.tly - ((double)y0 - 1.001) * g->cam.ph;
+                        const LeafHead Hm = leaf_head(S, leaf);
+                        cdp Mw = S.leaves + 16ull * leaf;
+                        Ray corner[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {                   // corners in order around the block
+                            const double jx = (c == 0 || c == 3) ? jx0 : jx1, jy = (c < 2) ? jy0 : jy1;
+                            const Ray w{g->cam.o[0], g->cam.o[1], g->cam.o[2], (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0],
+                                        (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1], (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2]};
+                            to_model(Mw, (Hm.flags & LF_XFORM) != 0, w, corner[c]);
+                        }
+                        const float ox = (float)corner[0].ox, oy = (float)corner[0].oy, oz = (float)corner[0].oz;
+                        bool reach = false;
+                        for (uint32_t b0 = 0; b0 < n_box; b0 += 64u) {
+                            const uint32_t bx = b0 + lane_id();
+                            bool in = bx < n_box;
+                            if (in) {
+                                const float* Bx = S.coarse_boxes + 6u * (first_box + bx);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {           // side plane through corner rays c and c+1, oriented by the opposite corner
+                                    const Ray& a = corner[c]; const Ray& bq = corner[(c + 1) & 3]; const Ray& opp = corner[(c + 2) & 3];
+                                    float nx = (float)(a.dy * bq.dz - a.dz * bq.dy), ny = (float)(a.dz * bq.dx - a.dx * bq.dz), nz = (float)(a.dx * bq.dy - a.dy * bq.dx);
+                                    const float side = nx * (float)opp.dx + ny * (float)opp.dy + nz * (float)opp.dz;
+                                    if (side < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+                                    // the box corner furthest along the inward normal
+                                    const float qx = (nx > 0.0f ? Bx[3] : Bx[0]) - ox, qy = (ny > 0.0f ? Bx[4] : Bx[1]) - oy, qz = (nz > 0.0f ? Bx[5] : Bx[2]) - oz;
+                                    const float d = nx * qx + ny * qy + nz * qz;
+                                    const float slack = 1e-4f * (fabsf(nx * qx) + fabsf(ny * qy) + fabsf(nz * qz));
+                                    if (d < -slack && side != 0.0f) in = false;     // wholly outside this side of the pyramid
+                                }
+                            }
+                            if (__any(in)) { reach = true; break; }
+                        }
+                        if (!reach) { if (half == 0) M.lo &= ~(1ull << bit); else M.hi &= ~(1ull << bit); }
+                    }
+                }
                 active = (M.lo | M.hi) != 0ull || S.n_items > 128;
             }
             if (active) keep_mask |= 1u << j;

@@ -266,7 +266,11 @@ struct Flattener {
             }
             float rf = (float)r; while ((double)rf < r) rf = std::nextafter(rf, std::numeric_limits<float>::infinity());
             float bits; std::memcpy(&bits, &mask, 4);
-            const float rec[8] = {(float)R.centre[0], (float)R.centre[1], (float)R.centre[2], rf, bits, 0.f, 0.f, 0.f};
+            float rec[8] = {(float)R.centre[0], (float)R.centre[1], (float)R.centre[2], rf, bits, 0.f, 0.f, 0.f};
+            if (out.leaves.size() == m.leaf_at + 1 && out.leaves[m.leaf_at].kind == ftd::LK_MESH) {   // a bare mesh: [5] first coarse box, [6] count, [7] its leaf
+                const uint32_t mesh = out.leaves[m.leaf_at].mesh, w[3] = {out.mesh_coarse[2 * mesh], out.mesh_coarse[2 * mesh + 1], (uint32_t)m.leaf_at};
+                std::memcpy(&rec[5], w, sizeof w);
+            }
             out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
             out.item_pc.push_back((uint32_t)m.prog_at | 0x80000000u);   // top bit: the item starts with its OP_CULL pair
         }
@@ -627,6 +631,49 @@ int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatSce
         if (mesh.bvh_root >= 0 && (int32_t)b.bvh_depth + 1 > out.stack_capacity) out.stack_capacity = (int32_t)b.bvh_depth + 1;
     }
     out.mesh_wide.push_back(wide_root);
+    {   // <= 64 boxes that together hold every triangle of the mesh: one level of the binary tree (BVH of a top-level Leaf, or the BSP itself)
+        const int32_t top = root < 0 ? mesh.bvh_root : root;
+        const uint32_t first = (uint32_t)(out.coarse_boxes.size() / 6);
+        uint32_t count = 0;
+        if (top >= 0 && top != INT32_MIN) {
+            std::vector<int32_t> frontier{top};
+            for (;;) {
+                std::vector<int32_t> next;
+                bool any_inner = false;
+                for (int32_t c : frontier) {
+                    if (c < 0) { next.push_back(c); continue; }
+                    any_inner = true;
+                    next.push_back(out.nodes[(size_t)c].left); next.push_back(out.nodes[(size_t)c].right);
+                }
+                if (!any_inner || next.size() > 64) break;
+                frontier.swap(next);
+            }
+            for (int32_t c : frontier) {
+                double lo[3] = {1e308, 1e308, 1e308}, hi[3] = {-1e308, -1e308, -1e308};
+                if (c >= 0) { const ftd::BspNode& nd = out.nodes[(size_t)c]; for (int a = 0; a < 3; ++a) { lo[a] = nd.bmin[a]; hi[a] = nd.bmax[a]; } }
+                else {
+                    const ftd::BspLeaf& L = out.bsp_leaves[(size_t)~c];
+                    for (uint32_t k = 0; k < L.n_tris; ++k) {
+                        const double* T = &out.tris[9 * (size_t)(L.first_tri + k)];
+                        for (int v = 0; v < 3; ++v) for (int a = 0; a < 3; ++a) {
+                            const double q = T[a] + (v == 1 ? T[3 + a] : v == 2 ? T[6 + a] : 0.0);
+                            lo[a] = std::min(lo[a], q); hi[a] = std::max(hi[a], q);
+                        }
+                    }
+                    if (L.n_tris == 0) continue;                                // an empty leaf holds nothing
+                }
+                float rec[6];
+                for (int a = 0; a < 3; ++a) {                                   // outward, with room for the float arithmetic of the test
+                    const double pad = 1e-5 * (std::fabs(lo[a]) + std::fabs(hi[a]) + (hi[a] - lo[a])) + 1e-30;
+                    rec[a] = std::nextafter((float)(lo[a] - pad), -std::numeric_limits<float>::infinity());
+                    rec[3 + a] = std::nextafter((float)(hi[a] + pad), std::numeric_limits<float>::infinity());
+                }
+                out.coarse_boxes.insert(out.coarse_boxes.end(), rec, rec + 6);
+                ++count;
+            }
+        }
+        out.mesh_coarse.push_back(first); out.mesh_coarse.push_back(count);
+    }
     return FT_OK;
 }
 

@@ -42,6 +42,8 @@ struct FlatScene {
     std::vector<uint32_t> tri_orig;   // 1 per triangle (see ft_flat.h)
     std::vector<double> wide;         // 28 doubles per 4-wide BVH node (ft_flat.h), walked by coherent wavefronts
     std::vector<int32_t> mesh_wide;   // per mesh: root of its 4-wide BVH, or INT32_MIN
+    std::vector<float> coarse_boxes;  // 6 floats per box (lo, hi; model space, rounded outward): <= 64 boxes per mesh that cover all its triangles
+    std::vector<uint32_t> mesh_coarse;// per mesh: first box, box count (0 = none) - k_classify tests pixel blocks against them
     std::vector<ftd::CullRecord> culls;
     std::vector<uint32_t> item_pc;    // program counter of every top-level item, in order, + one sentinel (the OP_END word)
     std::vector<float> cull_items;    // 8 floats per top-level item: centre, radius (rounded up; +inf = unbounded), row mask (bits), pad - the wave-level pre-test
