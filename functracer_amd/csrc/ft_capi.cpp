@@ -613,7 +613,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         double* const chunk_out = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
         if (classify) {
             timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, gen, c->d_active_ids.as<uint32_t>(), c->d_active_pos.as<uint32_t>(), &cc->pixels, chunk_out, whole ? 1 : 0, rcount); });
-            n_launches += 2;
+            n_launches += 1;
             gen.pixel_ids = c->d_active_ids.as<uint32_t>(); gen.pix_base = 0; gen.counts = &cc->pixels;
         }
         for (int b = 0; b <= last_bounce; ++b) {

@@ -1074,7 +1074,7 @@ FT_DEV uint32_t div_by(uint32_t a, double inv_b) { return (uint32_t)(((double)a 
 struct Pix { uint32_t n; double inv; };
 FT_DEV Pix pix_count(PrimaryArg g) {
     const PixCount* c = g->counts;
-    if (c) { const FT_CONST PixCount* cc = to_const_as(c); return {cc->n_pix, cc->inv_n_pix}; }
+    if (c) { const uint32_t n = to_const_as(c)->n_pix; return {n, 1.0 / (double)n}; }   // one division per batch is cheaper than a launch that stores the reciprocal
     return {g->n_pix, g->inv_n_pix};
 }
 
@@ -1580,8 +1580,6 @@ __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
     }
     wave_add(&my_stats(K->rc)->pixels_culled, culled);
 }
-// The reciprocal of the active count, once the count is final.
-__global__ void k_classify_finish(PixCount* counts) { counts->inv_n_pix = 1.0 / (double)counts->n_pix; }
 
 // ---------------------------------------------------------------------------------------------
 // k_tail: the end of the bounce loop as one launch.  Late bounces carry few, incoherent rays; run as closest / shade stages
@@ -1825,7 +1823,6 @@ void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list
     const ClassifyArgs a{S, gen_list, active_ids, active_pos, counts, out, rc, whole};
     const uint32_t n_runs = (gen_list.n_pix / 64u + kClassifyRun - 1) / kClassifyRun;
     hipLaunchKernelGGL(k_classify, dim3(blocks_for(n_runs * 64u, L.grid)), dim3(kBlock), 0, L.stream, a);
-    hipLaunchKernelGGL(k_classify_finish, dim3(1), dim3(1), 0, L.stream, counts);
 }
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
                  int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc) {
