@@ -51,8 +51,8 @@ def stdout_to_stderr():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="bunny")
     ap.add_argument("--res", type=int, nargs=2, default=None)
     ap.add_argument("--spp", type=int, default=None)

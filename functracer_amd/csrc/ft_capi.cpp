@@ -363,7 +363,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_coarse, f.coarse_boxes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 1))) != FT_OK) return rc;
+    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 2))) != FT_OK) return rc;   // + one slot's worth for the frame's PixCount
     FT_HIP(c, hipStreamSynchronize(c->stream));
     ftk::DevScene& S = c->dev_scene;
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
@@ -553,15 +553,15 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
         c->jitter_on_device = jit;
     }
-    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 1), c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 2), c->stream));
 
     // k_classify applies to pinhole cameras over whole 64-pixel blocks and scenes in which every top-level item is bounded
     bool classify = c->classify_pixels && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && pix_per_chunk % 64 == 0;
     for (size_t k = 0; classify && k + 1 < c->flat.item_pc.size(); ++k) if (!(c->flat.cull_items[8 * k + 3] < 1e30f)) classify = false;
     for (const Job& j : jobs) if (j.n_ids % 64u) classify = false;
     if (classify) {
-        if ((rc = ensure(c, c->d_active_ids, (size_t)pix_per_chunk * 4)) != FT_OK) return rc;
-        if ((rc = ensure(c, c->d_active_pos, (size_t)pix_per_chunk * 4)) != FT_OK) return rc;
+        if ((rc = ensure(c, c->d_active_ids, (size_t)n_pix_total * 4)) != FT_OK) return rc;
+        if ((rc = ensure(c, c->d_active_pos, (size_t)n_pix_total * 4)) != FT_OK) return rc;
     }
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
@@ -602,6 +602,15 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         boundary = b; boundary_fresh = true;
     };
     int n_chunks = 0, n_launches = 0;
+    // The whole frame is classified once; the chunks then take consecutive windows of the frame's ACTIVE pixel list, so a sparse
+    // frame is one chunk of real work and launches that find their window empty return at once.
+    ftk::PixCount* const frame_counts = reinterpret_cast<ftk::PixCount*>(rcount + ftk::kStatSlots + 1);
+    if (classify) {
+        const ftk::Primary all{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), 0u, (uint32_t)n_pix_total, spp, (uint32_t)res_h,
+                               (unsigned long long)seed, 1.0 / (double)n_pix_total, 1.0 / (double)res_h, nullptr};
+        timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, all, c->d_active_ids.as<uint32_t>(), c->d_active_pos.as<uint32_t>(), frame_counts, c->d_out.as<double>(), whole ? 1 : 0, rcount); });
+        ++n_launches;
+    }
     for (const Job& job : jobs) {
         ++n_chunks;
         const uint32_t n_pix = job.n_ids;
@@ -611,11 +620,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
                          (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
                          1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h), nullptr};
         double* const chunk_out = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
-        if (classify) {
-            timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, gen, c->d_active_ids.as<uint32_t>(), c->d_active_pos.as<uint32_t>(), &cc->pixels, chunk_out, whole ? 1 : 0, rcount); });
-            n_launches += 1;
-            gen.pixel_ids = c->d_active_ids.as<uint32_t>(); gen.pix_base = 0; gen.counts = &cc->pixels;
-        }
+        if (classify) { gen.pixel_ids = c->d_active_ids.as<uint32_t>(); gen.counts = frame_counts; }   // pix_base = job.id_base: the window's start
         for (int b = 0; b <= last_bounce; ++b) {
             timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, (uint32_t)c->tail_rays, cc, rcount); });
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
@@ -626,10 +631,10 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
             ++n_launches;
         }
         const uint32_t* out_index = !whole ? nullptr : (corner ? c->d_out_index.as<uint32_t>() : c->d_pixels.as<uint32_t>()) + job.out_base;
-        if (classify) out_index = whole ? c->d_active_ids.as<uint32_t>() : c->d_active_pos.as<uint32_t>();
         double* out_ptr = chunk_out;
+        if (classify) { out_index = (whole ? c->d_active_ids.as<uint32_t>() : c->d_active_pos.as<uint32_t>()) + job.id_base; out_ptr = c->d_out.as<double>(); }
         if (corner) timed(3, [&] { ftk::launch_blend_corner(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, job.w, job.h, out_index, out_ptr); });
-        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, classify ? &cc->pixels : nullptr, spp, out_index, out_ptr); });
+        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, classify ? frame_counts : nullptr, job.id_base, spp, out_index, out_ptr); });
         ++n_launches;
     }
     timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, ftk::kStatSlots); });

@@ -54,7 +54,6 @@ constexpr uint64_t kPixelIdBytes = 4, kTouchedBytes = 1, kListBytes = 4, kAccByt
 struct PixCount { uint32_t n_pix, pad; double inv_n_pix; };
 // Per-chunk device counters (zeroed before every chunk).
 struct ChunkCounters {
-    PixCount pixels;
     uint32_t n_rays[kMaxBounce + 2];   // rays queued for bounce k
     uint32_t n_hits[kMaxBounce + 2];   // compacted lit/unlit hit count of bounce k
     // Work cursors: kWorkGroups independent counters per kernel and bounce, one 64-byte line each (see ft_kernels.hip).
@@ -95,7 +94,8 @@ struct Primary {
     uint32_t stride;               // ids are y*stride + x: res_h for pixels, res_h + 1 for the corner grid of `samples corner`
     unsigned long long seed;       // keys the counter-based streams of soft shadows / depth of field
     double inv_n_pix, inv_stride;  // 1.0 / n_pix, 1.0 / stride (division-free index arithmetic, see div_by)
-    const PixCount* counts;        // non-null: pixel_ids is the chunk's ACTIVE pixel list (k_classify) and these replace n_pix / inv_n_pix
+    const PixCount* counts;        // non-null: pixel_ids is the FRAME's active pixel list (k_classify), counts->n_pix its length, and this chunk
+                                   // works on the window [pix_base, pix_base + n_pix) of it
 };
 // K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.  Bounce 0 also records, one
 // byte per sample, whether the primary ray hit anything (`touched`): untouched samples are Colour.Zero and their accumulator is
@@ -117,7 +117,7 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
                   double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
 // out_index == nullptr: pixel p is written at out_rgb + 3p (packed); else at out_rgb + 3*out_index[p] (in place in the frame).
-void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, int32_t spp, const uint32_t* out_index, double* out_rgb);
+void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, uint32_t first, int32_t spp, const uint32_t* out_index, double* out_rgb);
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
 void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
 // Sum the per-wave statistic slots 1..n_slots into slot 0 (one block).

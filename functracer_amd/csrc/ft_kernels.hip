@@ -1074,7 +1074,11 @@ FT_DEV uint32_t div_by(uint32_t a, double inv_b) { return (uint32_t)(((double)a 
 struct Pix { uint32_t n; double inv; };
 FT_DEV Pix pix_count(PrimaryArg g) {
     const PixCount* c = g->counts;
-    if (c) { const uint32_t n = to_const_as(c)->n_pix; return {n, 1.0 / (double)n}; }   // one division per batch is cheaper than a launch that stores the reciprocal
+    if (c) {                                                        // this chunk's window [pix_base, pix_base + n_pix) of the frame's active list
+        const uint32_t n_active = to_const_as(c)->n_pix, first = g->pix_base, cap = g->n_pix;
+        const uint32_t n = n_active > first ? (n_active - first < cap ? n_active - first : cap) : 0u;
+        return {n, 1.0 / (double)n};                                // one division per batch is cheaper than a launch that stores the reciprocal
+    }
     return {g->n_pix, g->inv_n_pix};
 }
 
@@ -1702,8 +1706,9 @@ __global__ __launch_bounds__(64) void k_reduce_stats(RenderCounters* slots, uint
 }
 
 __global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, const uint8_t* __restrict__ touched, uint32_t acc_stride, uint32_t n_pix_host, const PixCount* counts,
-                                                   int32_t spp, const uint32_t* __restrict__ out_index, double* __restrict__ out) {
-    const uint32_t n_pix = counts ? counts->n_pix : n_pix_host;     // active pixels of the chunk (k_classify) or all of them
+                                                   uint32_t first, int32_t spp, const uint32_t* __restrict__ out_index, double* __restrict__ out) {
+    uint32_t n_pix = n_pix_host;                                    // all pixels of the chunk, or its window of the frame's active list (k_classify)
+    if (counts) { const uint32_t n_active = counts->n_pix; n_pix = n_active > first ? (n_active - first < n_pix_host ? n_active - first : n_pix_host) : 0u; }
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
         double r = 0.0, g = 0.0, b = 0.0;                          // Array.average: sum from Zero in sample order, then DivideByInt
         for (int s = 0; s < spp; ++s) {
@@ -1829,8 +1834,8 @@ void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf 
     const TailArgs a{S, gen, {rays_even, rays_odd}, acc, cc, rc, acc_stride, max_depth, threshold};
     hipLaunchKernelGGL(tail_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
-void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, int32_t spp, const uint32_t* out_index, double* out_rgb) {
-    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, counts, spp, out_index, out_rgb);
+void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, uint32_t first, int32_t spp, const uint32_t* out_index, double* out_rgb) {
+    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, counts, first, spp, out_index, out_rgb);
 }
 void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb) {
     hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, w, h, out_index, out_rgb);
