@@ -9,7 +9,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats 
 cp $(ls gpurun_out/${tag}_stats/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats.csv
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d gpurun_out/${tag}_write -- $B > /dev/null 2>&1
-python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write --pixels 2073600 --spp 16 --frames 23 --active-pixels ${ACTIVE_PIXELS:-427392} > gpurun_out/${tag}_pmc_traffic.json
+ACTIVE_PIXELS=$(python3 -c "import json,sys; d=json.loads(open('gpurun_out/${tag}_bench_under_stats.json').read().strip().splitlines()[-1]); print(2073600 - d['rays_per_frame']['primary_resolved_per_64_pixel_block_rank0'] // 16)")
+python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write --pixels 2073600 --spp 16 --frames 23 --active-pixels $ACTIVE_PIXELS > gpurun_out/${tag}_pmc_traffic.json
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 -d gpurun_out/${tag}_va -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/${tag}_vb -- $B > /dev/null 2>&1
 python3 tools/pmc_valu.py gpurun_out/${tag}_va gpurun_out/${tag}_vb > gpurun_out/${tag}_pmc_valu.json
