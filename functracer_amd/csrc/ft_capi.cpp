@@ -41,7 +41,7 @@ struct ft_context {
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
     int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
-    int64_t tail_rays = 65536;       // a bounce that starts with fewer rays is finished by k_tail (0 = never)
+    int64_t tail_rays = 262144;      // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM
     DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_active_ids, d_active_pos, d_wide, d_mesh_wide, d_coarse;

@@ -1598,8 +1598,11 @@ struct TailArgs {
     uint32_t acc_stride; int32_t max_depth; uint32_t threshold;
 };
 
+#ifndef FT_TAIL_BLOCKS
+#define FT_TAIL_BLOCKS 2
+#endif
 template <bool FANCY, bool SOFT, bool MESH>
-__global__ __launch_bounds__(kBlock, 2) void k_tail(TailArgs) {
+__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(TailArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST TailArgs* K = kernel_args<TailArgs>();
     ChunkCounters* cc = K->cc;

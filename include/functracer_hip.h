@@ -139,7 +139,7 @@ const char* ft_last_error(const ft_context* ctx);
  * CSG), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around every
  * k_closest / k_shade launch, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
  * cannot reach any object are finished before any ray is generated), "tail_rays" (a bounce starting with fewer rays is finished by the tail
- * kernel in one launch; 0 = never; default 65536), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
+ * kernel in one launch; 0 = never; default 262144), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
 

@@ -458,7 +458,7 @@ def test_tail_kernel_changes_no_pixel_and_no_count(hip, name):
             frames.append(img)
             stats.append(st)
     finally:
-        hip.set_option("tail_rays", 65536)
+        hip.set_option("tail_rays", 262144)
     assert stats[0]["rays_tail"] == 0 and stats[1]["rays_tail"] > 0
     for img, st in zip(frames[1:], stats[1:]):
         assert np.array_equal(img, frames[0])
