@@ -250,9 +250,10 @@ class Context(SceneBuilder):
         return out
 
     def scene_info(self):
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 12)()
         self._check(self._lib.ft_debug_scene_info(self._ctx, out))
-        keys = ["leaves", "program_words", "meshes", "bsp_nodes", "bsp_leaves", "triangles", "csg_capacity", "stack_capacity"]
+        keys = ["leaves", "program_words", "meshes", "bsp_nodes", "bsp_leaves", "triangles", "csg_capacity", "stack_capacity", "items", "bounded_items",
+                "unbounded_other", "face_directions"]
         return dict(zip(keys, list(out)))
 
 

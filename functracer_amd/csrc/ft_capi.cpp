@@ -557,7 +557,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
 
     // k_classify applies to pinhole cameras over whole 64-pixel blocks and scenes in which every top-level item is bounded
     bool classify = c->classify_pixels && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && pix_per_chunk % 64 == 0;
-    for (size_t k = 0; classify && k + 1 < c->flat.item_pc.size(); ++k) if (!(c->flat.cull_items[8 * k + 3] < 1e30f)) classify = false;
+    if (c->flat.unbounded_other) classify = false;              // bounded items and bare planes only
     for (const Job& j : jobs) if (j.n_ids % 64u) classify = false;
     if (classify) {
         if ((rc = ensure(c, c->d_active_ids, (size_t)n_pix_total * 4)) != FT_OK) return rc;
@@ -756,12 +756,14 @@ int32_t ft_debug_blocked(ft_context* c, const double* origins, const double* dir
     return FT_OK;
 }
 
-int32_t ft_debug_scene_info(ft_context* c, int64_t out[8]) {
+int32_t ft_debug_scene_info(ft_context* c, int64_t out[12]) {
     if (!c || !out) return FT_ERR_INVALID;
     if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }
     const fth::FlatScene& f = c->flat;
     out[0] = (int64_t)f.leaves.size(); out[1] = (int64_t)f.program.size(); out[2] = (int64_t)f.meshes.size(); out[3] = (int64_t)f.nodes.size() - f.bvh_nodes;
     out[4] = (int64_t)f.bsp_leaves.size() - f.bvh_leaves; out[5] = (int64_t)(f.tris.size() / 9) - f.bvh_tris; out[6] = f.csg_capacity; out[7] = f.bsp_stack_capacity;   // BSP-only: excludes the device-side BVH
+    int64_t bounded = 0; for (size_t k = 0; k + 1 < f.item_pc.size(); ++k) if (f.cull_items[8 * k + 3] < 1e30f) ++bounded;
+    out[8] = (int64_t)f.item_pc.size() - 1; out[9] = bounded; out[10] = f.unbounded_other ? 1 : 0; out[11] = f.cull_bundle ? (int64_t)(f.cull_rows.size() / 3) : -1;
     return FT_OK;
 }
 

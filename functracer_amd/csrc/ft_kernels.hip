@@ -1518,6 +1518,22 @@ __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
                         const uint32_t n_box = __float_as_uint(I[6]);
                         if (n_box == 0u) continue;
                         const uint32_t first_box = __float_as_uint(I[5]), leaf = __float_as_uint(I[7]);
+                        if (n_box == kCoarseIsPlane) {
+                            // A bare plane (Plane.fs:9-33, y = 0 of its model space): t = -o.y / d.y is negative for every ray of the
+                            // block - so neither closest nor lightIsBlocked can use the hit - when o.y and d.y have the same sign and
+                            // |d.y| stays clear of the parallel-ray rule.  d.y is affine in the pixel, so its extremes over each pixel's
+                            // jitter square are at the square's corners (dlo / dhi hold them in WORLD space; the plane's row maps them).
+                            const LeafHead Hp = leaf_head(S, leaf);
+                            cdp Mp = S.leaves + 16ull * leaf;
+                            const bool xf = (Hp.flags & LF_XFORM) != 0;
+                            const double oy = xf ? Mp[4] * g->cam.o[0] + Mp[5] * g->cam.o[1] + Mp[6] * g->cam.o[2] + Mp[7] : g->cam.o[1];
+                            double lo = 0.0, hi = 0.0;
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) { const double ra = xf ? Mp[4 + a] : (a == 1 ? 1.0 : 0.0); const double u = ra * dlo[a], v = ra * dhi[a]; lo += fmin(u, v); hi += fmax(u, v); }
+                            const bool away = (oy > 0.0 && lo > 4.0 * kEps) || (oy < 0.0 && hi < -4.0 * kEps);
+                            if (!__any(!away)) { if (half == 0) M.lo &= ~(1ull << bit); else M.hi &= ~(1ull << bit); }
+                            continue;
+                        }
                         // pixel bounds of the block (+- one pixel of jitter), as image-plane coordinates
                         const float fpx = (float)px, fpy = (float)py;
                         const float x0 = wave_min(fpx), x1 = -wave_min(-fpx), y0 = wave_min(fpy), y1 = -wave_min(-fpy);

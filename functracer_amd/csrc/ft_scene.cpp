@@ -88,6 +88,7 @@ struct MatFn { int kind; const GraphNode* node; };   // GraphNode::MaterialF / H
 struct WalkCtx {
     Mat4 m2w = mat_identity(), w2m = mat_identity();
     bool xform = false;
+    bool bounds = true;                              // false under operand B of subtract / intersect: the result lies within operand A
     std::vector<MatFn> fns;                          // outermost first
 };
 
@@ -99,6 +100,7 @@ struct Flattener {
     int32_t status = FT_OK;
     int csg_depth = 0, max_csg_depth = 0;
     int cur_list = 0, max_list = 0;                  // static bound on the per-lane hit-list length
+    std::vector<bool> leaf_bounds;                   // per leaf: its box is part of its item's bounds (WalkCtx::bounds)
     std::map<const GraphNode*, size_t> image_base;   // image texture node -> offset of its pixels in out.tex_pixels
 
     Flattener(const SceneGraph& g_, FlatScene& o, std::string& e) : g(g_), out(o), err(e) {}
@@ -164,6 +166,7 @@ struct Flattener {
         L.flags = (flip ? ftd::LF_FLIP : 0u) | (c.xform ? ftd::LF_XFORM : 0u) | (out.materials[L.material].apply_lighting ? ftd::LF_LIT : 0u);
         uint32_t id = (uint32_t)out.leaves.size();
         out.leaves.push_back(L);
+        leaf_bounds.push_back(c.bounds);
         for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) out.m2w.push_back(c.m2w.a[4 * r + k]);
         out.program.push_back(ftd::make_op(in_csg ? ftd::OP_LEAF_PUSH : ftd::OP_LEAF_FOLD, id));
         if (in_csg) { cur_list += max_hits; if (cur_list > max_list) max_list = cur_list; }
@@ -212,17 +215,21 @@ struct Flattener {
             default: return false;                                  // LK_PLANE: unbounded
         }
     }
-    void unbounded_item(size_t prog_at) {
+    void unbounded_item(size_t prog_at, size_t leaf_at) {
         out.item_pc.push_back((uint32_t)prog_at);
         ftd::CullRecord never{};                                    // cull records are indexed by item: this one can never report a miss
         never.radius2 = std::numeric_limits<double>::infinity();
         out.culls.push_back(never);
-        const float rec[8] = {0.f, 0.f, 0.f, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0.f, 0.f};
+        float rec[8] = {0.f, 0.f, 0.f, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0.f, 0.f};
+        if (out.leaves.size() == leaf_at + 1 && out.leaves[leaf_at].kind == ftd::LK_PLANE) {   // a bare plane: k_classify has an exact test for it
+            const uint32_t w[2] = {ftd::kCoarseIsPlane, (uint32_t)leaf_at};
+            std::memcpy(&rec[6], w, sizeof w);
+        } else out.unbounded_other = true;
         out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
     }
     void end_item(const ItemMark& m) {
         if (!m.open) return;
-        auto drop = [&]() { out.program.erase(out.program.begin() + (long)m.prog_at, out.program.begin() + (long)m.prog_at + 2); if (out.program.size() > m.prog_at) unbounded_item(m.prog_at); };
+        auto drop = [&]() { out.program.erase(out.program.begin() + (long)m.prog_at, out.program.begin() + (long)m.prog_at + 2); if (out.program.size() > m.prog_at) unbounded_item(m.prog_at, m.leaf_at); };
         if (status != FT_OK || out.leaves.size() == m.leaf_at) { drop(); return; }
         const double inf = std::numeric_limits<double>::infinity();
         double blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
@@ -230,9 +237,12 @@ struct Flattener {
         for (size_t li = m.leaf_at; li < out.leaves.size(); ++li) {
             const ftd::Leaf& L = out.leaves[li];
             double lo[3], hi[3];
-            if (!model_box(L, lo, hi)) { drop(); return; }
+            // A - B and A & B lie within A (Csg.fs:27-44 never keep a B hit outside A), so operand B does not widen the item's
+            // bounds; its face directions still count (a parallel-ray hit of Plane.fs:13-16 can sit anywhere).
+            const bool bounding = leaf_bounds[li];
+            if (bounding && !model_box(L, lo, hi)) { drop(); return; }
             const double* W = &out.m2w[12 * li];
-            for (int corner = 0; corner < 8; ++corner) {
+            for (int corner = 0; bounding && corner < 8; ++corner) {
                 const double x = (corner & 1) ? hi[0] : lo[0], y = (corner & 2) ? hi[1] : lo[1], z = (corner & 4) ? hi[2] : lo[2];
                 std::array<double, 3> q = {W[0] * x + W[1] * y + W[2] * z + W[3], W[4] * x + W[5] * y + W[6] * z + W[7], W[8] * x + W[9] * y + W[10] * z + W[11]};
                 for (int a = 0; a < 3; ++a) { if (!(std::fabs(q[a]) < 1e300)) { drop(); return; } if (q[a] < blo[a]) blo[a] = q[a]; if (q[a] > bhi[a]) bhi[a] = q[a]; }
@@ -243,18 +253,21 @@ struct Flattener {
                 for (auto& e : rows) if (e == v) return;
                 rows.push_back(v);
             };
-            if (L.kind == ftd::LK_SQUARE || L.kind == ftd::LK_CIRCLE || L.kind == ftd::LK_SOLIDCYL) add_row(1);
+            if (L.kind == ftd::LK_SQUARE || L.kind == ftd::LK_CIRCLE || L.kind == ftd::LK_SOLIDCYL || L.kind == ftd::LK_PLANE) add_row(1);
             if (L.kind == ftd::LK_CUBE) { add_row(0); add_row(1); add_row(2); }
         }
-        if (rows.size() > 6) { drop(); return; }
+        // More face directions than a CullRecord holds: no per-ray OP_CULL for this item, but the wave-level tests (which keep the
+        // directions in a scene-wide table and a mask per item) still get its bounding sphere.
+        const bool exact = rows.size() <= 6;
+        if (!exact) out.program.erase(out.program.begin() + (long)m.prog_at, out.program.begin() + (long)m.prog_at + 2);
         ftd::CullRecord R{};
         double r2 = 0.0;
         for (int a = 0; a < 3; ++a) R.centre[a] = 0.5 * (blo[a] + bhi[a]);
         for (auto& q : pts) { double d2 = 0; for (int a = 0; a < 3; ++a) d2 += (q[a] - R.centre[a]) * (q[a] - R.centre[a]); if (d2 > r2) r2 = d2; }
         const double r = std::sqrt(r2) * (1.0 + 1e-6) + 1e-9;
-        R.radius2 = r * r;
-        R.n_rows = (double)rows.size();
-        for (size_t k = 0; k < rows.size(); ++k) for (int a = 0; a < 3; ++a) R.rows[k][a] = rows[k][a];
+        R.radius2 = exact ? r * r : inf;                            // inf: the per-ray test (were it asked) can never report a miss
+        R.n_rows = exact ? (double)rows.size() : 0.0;
+        for (size_t k = 0; exact && k < rows.size(); ++k) for (int a = 0; a < 3; ++a) R.rows[k][a] = rows[k][a];
         out.culls.push_back(R);
         {   // compact copy for the wave-level pre-test (k_closest / k_shade, bundle_cull)
             uint32_t mask = 0;
@@ -272,10 +285,25 @@ struct Flattener {
                 std::memcpy(&rec[5], w, sizeof w);
             }
             out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
-            out.item_pc.push_back((uint32_t)m.prog_at | 0x80000000u);   // top bit: the item starts with its OP_CULL pair
+            out.item_pc.push_back((uint32_t)m.prog_at | (exact ? 0x80000000u : 0u));   // top bit: the item starts with its OP_CULL pair
         }
+        if (!exact) return;
         out.program[m.prog_at] = ftd::make_op(ftd::OP_CULL, (uint32_t)out.culls.size() - 1);
         out.program[m.prog_at + 1] = (uint32_t)(out.program.size() - (m.prog_at + 2));
+    }
+
+    // A solid every line crosses an even number of times: sphere, cube, solidCylinder and their CSG / group combinations.  Only then
+    // does A - B (A & B) lie within A for the purposes of the item bounds: the reference decides "inside A" by counting crossings
+    // along the whole LINE (Csg.fs:81-93, hits at negative t included), so a flat or open operand A (square, circle, cone,
+    // cylinder, triangles) crossed once BEHIND the ray origin leaves the ray "inside A" and operand B's hits far from A are kept.
+    bool closed_solid(int32_t id) const {
+        const GraphNode& n = g.nodes[id];
+        switch (n.kind) {
+            case GraphNode::Prim: return n.prim == FT_PRIM_SPHERE || n.prim == FT_PRIM_CUBE || n.prim == FT_PRIM_SOLID_CYLINDER;
+            case GraphNode::Transform: case GraphNode::MaterialF: case GraphNode::HueShift: case GraphNode::IgnoreLight: case GraphNode::Texture: return closed_solid(n.children[0]);
+            case GraphNode::Group: case GraphNode::Csg: { for (int32_t ch : n.children) if (!closed_solid(ch)) return false; return !n.children.empty(); }
+            default: return false;                                  // triangles, meshes
+        }
     }
 
     // A primitive (not a mesh) under any chain of single-child scene functions: one leaf with at most a few hits.
@@ -366,10 +394,12 @@ struct Flattener {
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
                 walk(n.children[0], c, true);
                 const bool a_gates = n.op == FT_CSG_SUBTRACT || n.op == FT_CSG_INTERSECT;   // no A hit => empty result
+                WalkCtx cb = c;
+                if (a_gates && closed_solid(n.children[0])) cb.bounds = false;
                 const size_t skip_at = out.program.size();
                 if (a_gates) out.program.push_back(ftd::make_op(ftd::OP_SKIP_IF_EMPTY, 0));
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
-                walk(n.children[1], c, true);
+                walk(n.children[1], cb, true);
                 out.program.push_back(ftd::make_op(ftd::OP_CSG, (uint32_t)n.op));
                 if (a_gates) out.program[skip_at] = ftd::make_op(ftd::OP_SKIP_IF_EMPTY, (uint32_t)(out.program.size() - skip_at - 1));
                 --csg_depth;

@@ -201,11 +201,12 @@ int32_t ft_debug_blocked(ft_context* ctx, const double* origins, const double* d
 
 /* Host-logic test hooks (no device work): a context that can build, flatten and BSP-compile a scene
  * but whose render/debug calls fail with FT_ERR_NO_DEVICE; flattened-scene sizes
- * (out = leaves, program words, meshes, bsp nodes, bsp leaves, triangles, csg capacity, stack capacity);
+ * (out = leaves, program words, meshes, bsp nodes, bsp leaves, triangles, csg capacity, stack capacity, top-level items,
+ * items with a bounding sphere, 1 if some unbounded item is not a bare plane, distinct face directions or -1);
  * and Triangle.slice (Triangle.fs:24-41) as the BSP builder implements it (9 doubles per triangle,
  * at most 2 triangles per side). */
 int32_t ft_create_host_only(ft_context** out);
-int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[8]);
+int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[12]);
 int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9],
                        double above[18], int32_t* n_above, double below[18], int32_t* n_below);
 /* HIP-event time per stage over the last ft_render: index 1 closest, 2 shade (and the tail kernel); with "timing" = 2 also
