@@ -253,7 +253,7 @@ class Context(SceneBuilder):
         out = (C.c_int64 * 12)()
         self._check(self._lib.ft_debug_scene_info(self._ctx, out))
         keys = ["leaves", "program_words", "meshes", "bsp_nodes", "bsp_leaves", "triangles", "csg_capacity", "stack_capacity", "items", "bounded_items",
-                "unbounded_other", "face_directions"]
+                "unbounded", "face_directions"]
         return dict(zip(keys, list(out)))
 
 

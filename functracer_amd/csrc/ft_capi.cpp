@@ -44,7 +44,7 @@ struct ft_context {
     int64_t tail_rays = 262144;      // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_active_ids, d_active_pos, d_wide, d_mesh_wide, d_coarse;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_active_ids, d_active_pos, d_wide, d_mesh_wide, d_coarse, d_block_flags;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_touched, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
@@ -201,7 +201,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_active_ids, &c->d_active_pos, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_active_ids, &c->d_active_pos, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_block_flags, &c->d_out_index,
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -557,11 +557,15 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
 
     // k_classify applies to pinhole cameras over whole 64-pixel blocks and scenes in which every top-level item is bounded
     bool classify = c->classify_pixels && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && pix_per_chunk % 64 == 0;
-    if (c->flat.unbounded_other) classify = false;              // bounded items and bare planes only
+    if (c->flat.unbounded) classify = false;                    // measured: with a ground plane in view an exact plane test finds the sky blocks (20 % of night-house)
+                                                                  // but the denser first chunk makes k_shade slower than the blocks save
     for (const Job& j : jobs) if (j.n_ids % 64u) classify = false;
     if (classify) {
         if ((rc = ensure(c, c->d_active_ids, (size_t)n_pix_total * 4)) != FT_OK) return rc;
         if ((rc = ensure(c, c->d_active_pos, (size_t)n_pix_total * 4)) != FT_OK) return rc;
+        const size_t n_blocks = (size_t)n_pix_total / 64, n_seg = (n_blocks + ftk::kClassifySegmentBlocks - 1) / ftk::kClassifySegmentBlocks;
+        if ((rc = ensure(c, c->d_block_flags, n_seg * 4 + n_blocks)) != FT_OK) return rc;             // segment counts, then one byte per block
+        FT_HIP(c, hipMemsetAsync(c->d_block_flags.p, 0, n_seg * 4, c->stream));
     }
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
@@ -608,8 +612,10 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     if (classify) {
         const ftk::Primary all{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), 0u, (uint32_t)n_pix_total, spp, (uint32_t)res_h,
                                (unsigned long long)seed, 1.0 / (double)n_pix_total, 1.0 / (double)res_h, nullptr};
-        timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, all, c->d_active_ids.as<uint32_t>(), c->d_active_pos.as<uint32_t>(), frame_counts, c->d_out.as<double>(), whole ? 1 : 0, rcount); });
-        ++n_launches;
+        const size_t n_seg = ((size_t)n_pix_total / 64 + ftk::kClassifySegmentBlocks - 1) / ftk::kClassifySegmentBlocks;
+        timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, all, c->d_block_flags.as<uint8_t>() + n_seg * 4, c->d_block_flags.as<uint32_t>(), c->d_active_ids.as<uint32_t>(),
+                                            c->d_active_pos.as<uint32_t>(), frame_counts, c->d_out.as<double>(), whole ? 1 : 0, rcount); });
+        n_launches += 2;
     }
     for (const Job& job : jobs) {
         ++n_chunks;
@@ -763,7 +769,7 @@ int32_t ft_debug_scene_info(ft_context* c, int64_t out[12]) {
     out[0] = (int64_t)f.leaves.size(); out[1] = (int64_t)f.program.size(); out[2] = (int64_t)f.meshes.size(); out[3] = (int64_t)f.nodes.size() - f.bvh_nodes;
     out[4] = (int64_t)f.bsp_leaves.size() - f.bvh_leaves; out[5] = (int64_t)(f.tris.size() / 9) - f.bvh_tris; out[6] = f.csg_capacity; out[7] = f.bsp_stack_capacity;   // BSP-only: excludes the device-side BVH
     int64_t bounded = 0; for (size_t k = 0; k + 1 < f.item_pc.size(); ++k) if (f.cull_items[8 * k + 3] < 1e30f) ++bounded;
-    out[8] = (int64_t)f.item_pc.size() - 1; out[9] = bounded; out[10] = f.unbounded_other ? 1 : 0; out[11] = f.cull_bundle ? (int64_t)(f.cull_rows.size() / 3) : -1;
+    out[8] = (int64_t)f.item_pc.size() - 1; out[9] = bounded; out[10] = f.unbounded ? 1 : 0; out[11] = f.cull_bundle ? (int64_t)(f.cull_rows.size() / 3) : -1;
     return FT_OK;
 }
 

@@ -106,8 +106,9 @@ void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayB
 // K1: pixel-block classification.  A block of 64 pixels (all its samples) whose ray bundle cannot reach any top-level item is
 // finished on the spot (its output pixels are written as Colour.Zero); the others are compacted into the chunk's active
 // pixel list, which is all the later stages see.
-void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint32_t* active_ids, uint32_t* active_pos, PixCount* counts,
-                     double* out, int whole, RenderCounters* rc);
+void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint8_t* block_active, uint32_t* segment_count, uint32_t* active_ids,
+                     uint32_t* active_pos, PixCount* counts, double* out, int whole, RenderCounters* rc);
+constexpr uint32_t kClassifySegmentBlocks = 256;               // blocks per compaction segment (ft_kernels.hip: kSegmentBlocks)
 // Tail of the bounce loop (k_tail): once a bounce has fewer than `threshold` rays the per-bounce stages stand down and this one
 // launch follows every remaining path to its end inside registers.
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,

@@ -88,7 +88,6 @@ struct Mesh {
 //   [24], [25]     = int32 child[4]: >= 0 wide node, < 0 ~leaf index, INT32_MIN empty slot
 //   [26]           = uint32 axes: split axis of the binary node | of its left child << 8 | of its right child << 16
 constexpr int kWideNodeDoubles = 28;
-constexpr uint32_t kCoarseIsPlane = 0xFFFFFFFFu;   // FlatScene::cull_items[8k + 6] of a bare plane (in place of a coarse-box count)
 struct BspNode {           // 64 bytes; BspMesh.fs:12-19 (also used for BVH nodes)
     double bmin[3], bmax[3];
     int32_t left, right;   // >= 0 branch node; < 0: ~leaf index

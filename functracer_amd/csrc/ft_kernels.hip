@@ -1082,8 +1082,7 @@ FT_DEV Pix pix_count(PrimaryArg g) {
     return {g->n_pix, g->inv_n_pix};
 }
 
-FT_DEV unsigned long long sample_id(PrimaryArg g, uint32_t slot) {
-    const Pix px = pix_count(g);
+FT_DEV unsigned long long sample_id(PrimaryArg g, const Pix& px, uint32_t slot) {
     const uint32_t s = div_by(slot, px.inv), pl = slot - s * px.n;
     return (unsigned long long)g->pixel_ids[g->pix_base + pl] * (unsigned long long)g->spp + s;
 }
@@ -1091,15 +1090,14 @@ FT_DEV unsigned long long sample_id(PrimaryArg g, uint32_t slot) {
 // Primary rays are never stored: bounce 0 of k_closest / k_shade regenerates them from the sample index
 // (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
 // 64 pixels of one 8x8 block for one jitter offset).
-FT_DEV uint32_t primary_pixel(PrimaryArg g, uint32_t i) {            // the one memory access a primary ray needs
-    const Pix px = pix_count(g);
+FT_DEV uint32_t primary_pixel(PrimaryArg g, const Pix& px, uint32_t i) {   // the one memory access a primary ray needs
     const uint32_t s = div_by(i, px.inv), pl = i - s * px.n;
     return g->pixel_ids[g->pix_base + pl];
 }
 // `uniform_s`: all 64 lanes of the batch share one jitter offset (n_pix is a multiple of 64): it is then read
 // through a scalar load, which does not queue behind the wave's outstanding vector stores.
-FT_DEV Ray primary_ray_from(PrimaryArg g, uint32_t i, uint32_t pid, bool uniform_s) {
-    const uint32_t s = div_by(i, pix_count(g).inv);
+FT_DEV Ray primary_ray_from(PrimaryArg g, const Pix& count, uint32_t i, uint32_t pid, bool uniform_s) {
+    const uint32_t s = div_by(i, count.inv);
     const uint32_t py = div_by(pid, g->inv_stride), px = pid - py * g->stride;
     const double centre_x = g->cam.tlx + (double)px * g->cam.pw, centre_y = g->cam.tly - (double)py * g->cam.ph;
     double ox, oy;
@@ -1117,7 +1115,7 @@ FT_DEV Ray primary_ray_from(PrimaryArg g, uint32_t i, uint32_t pid, bool uniform
     }
     return r;
 }
-FT_DEV Ray primary_ray(PrimaryArg g, uint32_t i) { return primary_ray_from(g, i, primary_pixel(g, i), false); }
+FT_DEV Ray primary_ray(PrimaryArg g, const Pix& px, uint32_t i) { return primary_ray_from(g, px, i, primary_pixel(g, px, i), false); }
 
 struct ClosestArgs {
     DevScene S; Primary gen; RayBuf rays; HitBuf hits;
@@ -1134,7 +1132,8 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
     const Scene S = scene_view(K->S);
     const int bounce = K->bounce;
     ChunkCounters* cc = K->cc;
-    const uint32_t n_pix = pix_count(&K->gen).n;
+    const Pix px = pix_count(&K->gen);                              // once per launch: the count sits two dependent loads away
+    const uint32_t n_pix = px.n;
     const uint32_t n = bounce == 0 ? n_pix * (uint32_t)K->gen.spp : cc->n_rays[bounce];
     if (bounce > 0 && n < K->tail_threshold) return;               // few rays left: k_tail follows them to the end (nothing is spawned after this bounce)
     const uint32_t B = batch_lanes_for(n);
@@ -1168,7 +1167,7 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
     BatchCursor cursor(&cc->work_trace[bounce][0]);
     uint32_t bi = cursor.grab(), bi_next = cursor.grab();           // two deep: the index after next is in flight while this batch runs
     uint32_t pid_next = 0;
-    if (bounce == 0 && bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, bi * B + lane_id());
+    if (bounce == 0 && bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, px, bi * B + lane_id());
     for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
         const uint32_t base = bi * B;
         const uint32_t i = base + lane_id();
@@ -1178,9 +1177,9 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
         Ray r{0, 0, 0, 0, 0, 0};
         {
             const FT_CONST ClosestArgs* Kb = fresh(K);              // camera, pixel list, ray buffers: loaded here, dead before the trace
-            if (bounce == 0 && bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, bi_next * B + lane_id());
+            if (bounce == 0 && bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, px, bi_next * B + lane_id());
             if (q.active) {
-                if (bounce == 0) r = primary_ray_from(&Kb->gen, i, pid, uniform_s);
+                if (bounce == 0) r = primary_ray_from(&Kb->gen, px, i, pid, uniform_s);
                 else { const FT_CONST RayBuf& rays = Kb->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; }
                 r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
             }
@@ -1349,6 +1348,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
     const int bounce = K->bounce;
     ChunkCounters* cc = K->cc;
     const uint32_t n = cc->n_hits[bounce];
+    const Pix px = pix_count(&K->gen);                              // once per launch: the count sits two dependent loads away
     const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
     const uint32_t B = batch_lanes_for(n);
@@ -1367,14 +1367,14 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
             const uint32_t i = Kb->hit_list[j];
             Ray r;
             uint32_t slot;
-            if (bounce == 0) { r = primary_ray(&Kb->gen, i); slot = i; }
+            if (bounce == 0) { r = primary_ray(&Kb->gen, px, i); slot = i; }
             else { const FT_CONST RayBuf& rays = Kb->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; slot = rays.slot[i]; }
             const FT_CONST HitBuf& hits = Kb->hits;
             // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
             const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
             sf = surface_at<FANCY>(S, ro, hits.t[i], hits.id0[i], hits.id1[i]);
             lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
-            if (SOFT) sample = sample_id(&Kb->gen, slot);
+            if (SOFT) sample = sample_id(&Kb->gen, px, slot);
         }
         unsigned long long vis_lo, vis_hi;                         // byte l = occluded shadow samples of light l
         light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, bounce, bounce == 0 && K->S.coherent_waves != 0, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
         const FT_CONST ShadeArgs* K2 = fresh(K);
         if (active) {
             const uint32_t i = K2->hit_list[j];
-            if (bounce == 0) { r = primary_ray(&K2->gen, i); w = 1.0; slot = i; }
+            if (bounce == 0) { r = primary_ray(&K2->gen, px, i); w = 1.0; slot = i; }
             else { const FT_CONST RayBuf& rays = K2->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i]; }
         }
         MaterialV mat = material_at(S, sf.material);               // per-lane gather (64 B records, L1/L2 resident)
@@ -1444,8 +1444,9 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
 // this for pinhole cameras over whole 64-pixel blocks and scenes made of bounded items.
 struct ClassifyArgs {
     DevScene S; Primary gen;                                        // gen.pixel_ids / pix_base / n_pix: the chunk's full pixel list
-    uint32_t* active_ids; uint32_t* active_pos; PixCount* counts; double* out; RenderCounters* rc; int32_t whole;
+    uint8_t* block_active; uint32_t* segment_count; double* out; RenderCounters* rc; int32_t whole;
 };
+constexpr uint32_t kSegmentBlocks = 256;                            // blocks per compaction segment (one k_compact workgroup)
 constexpr uint32_t kClassifyRun = 4;                                // consecutive blocks per wave: one list reservation for all of them
 
 __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
@@ -1518,22 +1519,6 @@ __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
                         const uint32_t n_box = __float_as_uint(I[6]);
                         if (n_box == 0u) continue;
                         const uint32_t first_box = __float_as_uint(I[5]), leaf = __float_as_uint(I[7]);
-                        if (n_box == kCoarseIsPlane) {
-                            // A bare plane (Plane.fs:9-33, y = 0 of its model space): t = -o.y / d.y is negative for every ray of the
-                            // block - so neither closest nor lightIsBlocked can use the hit - when o.y and d.y have the same sign and
-                            // |d.y| stays clear of the parallel-ray rule.  d.y is affine in the pixel, so its extremes over each pixel's
-                            // jitter square are at the square's corners (dlo / dhi hold them in WORLD space; the plane's row maps them).
-                            const LeafHead Hp = leaf_head(S, leaf);
-                            cdp Mp = S.leaves + 16ull * leaf;
-                            const bool xf = (Hp.flags & LF_XFORM) != 0;
-                            const double oy = xf ? Mp[4] * g->cam.o[0] + Mp[5] * g->cam.o[1] + Mp[6] * g->cam.o[2] + Mp[7] : g->cam.o[1];
-                            double lo = 0.0, hi = 0.0;
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) { const double ra = xf ? Mp[4 + a] : (a == 1 ? 1.0 : 0.0); const double u = ra * dlo[a], v = ra * dhi[a]; lo += fmin(u, v); hi += fmax(u, v); }
-                            const bool away = (oy > 0.0 && lo > 4.0 * kEps) || (oy < 0.0 && hi < -4.0 * kEps);
-                            if (!__any(!away)) { if (half == 0) M.lo &= ~(1ull << bit); else M.hi &= ~(1ull << bit); }
-                            continue;
-                        }
                         // pixel bounds of the block (+- one pixel of jitter), as image-plane coordinates
                         const float fpx = (float)px, fpy = (float)py;
                         const float x0 = wave_min(fpx), x1 = -wave_min(-fpx), y0 = wave_min(fpy), y1 = -wave_min(-fpy);
@@ -1584,21 +1569,50 @@ __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
                 out[3 * o] = 0.0; out[3 * o + 1] = 0.0; out[3 * o + 2] = 0.0;
             }
         }
+        // Verdicts go to a byte per block and a count per segment of 256 blocks; k_compact turns them into the active list IN BLOCK
+        // ORDER (an atomic cursor here would scatter neighbouring blocks over the list, and later stages batch by list position).
+        if (lane_id() < kClassifyRun && run + lane_id() < n_blocks) K->block_active[run + lane_id()] = (uint8_t)((keep_mask >> lane_id()) & 1u);
         const uint32_t n_keep = (uint32_t)__popc(keep_mask);
-        if (n_keep) {
-            uint32_t base = 0;
-            if (lane_id() == 0) base = atomicAdd(&K->counts->n_pix, 64u * n_keep);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-            for (uint32_t j = 0; j < kClassifyRun; ++j) {
-                if (!((keep_mask >> j) & 1u)) continue;
-                K->active_ids[base + lane_id()] = pid_of[j];
-                K->active_pos[base + lane_id()] = (run + j) * 64u + lane_id();
-                base += 64u;
-            }
-        }
+        if (n_keep && lane_id() == 0) atomicAdd(&K->segment_count[run / kSegmentBlocks], n_keep);     // a run never straddles a segment
     }
     wave_add(&my_stats(K->rc)->pixels_culled, culled);
+}
+
+// k_compact: the active pixel list, in block order.  Workgroup s owns segment s (256 blocks): its first list position is the
+// sum of the counts of the segments before it, the rank of a block inside the segment comes from the flags, and each wave
+// then copies the 64 pixel ids of its blocks (coalesced).  The last segment publishes the length of the list.
+struct CompactArgs {
+    const uint32_t* pixel_ids; const uint8_t* block_active; const uint32_t* segment_count;
+    uint32_t* active_ids; uint32_t* active_pos; PixCount* counts; uint32_t n_blocks, n_segments;
+};
+__global__ __launch_bounds__(kBlock) void k_compact(CompactArgs a) {
+    __shared__ uint32_t partial[kBlock / 64];
+    __shared__ uint32_t dst_of[kSegmentBlocks];
+    const uint32_t seg = blockIdx.x, t = threadIdx.x, wave = t / 64;
+    uint32_t before = 0;
+    for (uint32_t j = t; j < seg; j += kBlock) before += a.segment_count[j];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if (lane_id() == 0) partial[wave] = before;
+    __syncthreads();
+    const uint32_t base = partial[0] + partial[1] + partial[2] + partial[3];
+    __syncthreads();
+    const uint32_t blk = seg * kSegmentBlocks + t;
+    const bool on = blk < a.n_blocks && a.block_active[blk] != 0;
+    const unsigned long long m = __ballot(on);
+    if (lane_id() == 0) partial[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t rank = lanes_below(m);
+    for (uint32_t w = 0; w < wave; ++w) rank += partial[w];
+    dst_of[t] = on ? base + rank : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = wave; k < kSegmentBlocks; k += kBlock / 64) {
+        const uint32_t d = dst_of[k];
+        if (d == 0xFFFFFFFFu) continue;
+        const uint32_t src = (seg * kSegmentBlocks + k) * 64u + lane_id();
+        a.active_ids[d * 64u + lane_id()] = a.pixel_ids[src];
+        a.active_pos[d * 64u + lane_id()] = src;
+    }
+    if (seg + 1 == a.n_segments && t == 0) a.counts->n_pix = 64u * (base + partial[0] + partial[1] + partial[2] + partial[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1626,6 +1640,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(Tai
     int k0 = 0; uint32_t n = 0;
     for (int k = 1; k <= max_depth; ++k) { const uint32_t nk = cc->n_rays[k]; if (nk > 0u && nk < K->threshold) { k0 = k; n = nk; break; } }
     if (k0 == 0) return;
+    const Pix px = pix_count(&K->gen);
     const Scene S = scene_view(K->S);
     const int n_lights = S.n_lights;
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0, n_in_wave = 0;
@@ -1663,7 +1678,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(Tai
             if (alive) {
                 sf = surface_at<FANCY>(S, ro, q.best_t, q.id0, q.id1);
                 lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
-                if (SOFT) sample = sample_id(&fresh(K)->gen, slot);
+                if (SOFT) sample = sample_id(&fresh(K)->gen, px, slot);
             }
             unsigned long long vis_lo, vis_hi;
             light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, depth, false, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
@@ -1842,11 +1857,13 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
     const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, cc, rc, acc_stride, bounce, max_depth};
     hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
-void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint32_t* active_ids, uint32_t* active_pos, PixCount* counts,
-                     double* out, int whole, RenderCounters* rc) {
-    const ClassifyArgs a{S, gen_list, active_ids, active_pos, counts, out, rc, whole};
-    const uint32_t n_runs = (gen_list.n_pix / 64u + kClassifyRun - 1) / kClassifyRun;
+void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint8_t* block_active, uint32_t* segment_count, uint32_t* active_ids,
+                     uint32_t* active_pos, PixCount* counts, double* out, int whole, RenderCounters* rc) {
+    const ClassifyArgs a{S, gen_list, block_active, segment_count, out, rc, whole};
+    const uint32_t n_blocks = gen_list.n_pix / 64u, n_runs = (n_blocks + kClassifyRun - 1) / kClassifyRun, n_segments = (n_blocks + kSegmentBlocks - 1) / kSegmentBlocks;
     hipLaunchKernelGGL(k_classify, dim3(blocks_for(n_runs * 64u, L.grid)), dim3(kBlock), 0, L.stream, a);
+    const CompactArgs cmp{gen_list.pixel_ids + gen_list.pix_base, block_active, segment_count, active_ids, active_pos, counts, n_blocks, n_segments};
+    hipLaunchKernelGGL(k_compact, dim3(n_segments), dim3(kBlock), 0, L.stream, cmp);
 }
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
                  int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc) {

@@ -220,11 +220,9 @@ struct Flattener {
         ftd::CullRecord never{};                                    // cull records are indexed by item: this one can never report a miss
         never.radius2 = std::numeric_limits<double>::infinity();
         out.culls.push_back(never);
-        float rec[8] = {0.f, 0.f, 0.f, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0.f, 0.f};
-        if (out.leaves.size() == leaf_at + 1 && out.leaves[leaf_at].kind == ftd::LK_PLANE) {   // a bare plane: k_classify has an exact test for it
-            const uint32_t w[2] = {ftd::kCoarseIsPlane, (uint32_t)leaf_at};
-            std::memcpy(&rec[6], w, sizeof w);
-        } else out.unbounded_other = true;
+        const float rec[8] = {0.f, 0.f, 0.f, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0.f, 0.f};
+        (void)leaf_at;
+        out.unbounded = true;
         out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
     }
     void end_item(const ItemMark& m) {

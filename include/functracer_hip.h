@@ -202,7 +202,7 @@ int32_t ft_debug_blocked(ft_context* ctx, const double* origins, const double* d
 /* Host-logic test hooks (no device work): a context that can build, flatten and BSP-compile a scene
  * but whose render/debug calls fail with FT_ERR_NO_DEVICE; flattened-scene sizes
  * (out = leaves, program words, meshes, bsp nodes, bsp leaves, triangles, csg capacity, stack capacity, top-level items,
- * items with a bounding sphere, 1 if some unbounded item is not a bare plane, distinct face directions or -1);
+ * items with a bounding sphere, 1 if some item is unbounded, distinct face directions or -1);
  * and Triangle.slice (Triangle.fs:24-41) as the BSP builder implements it (9 doubles per triangle,
  * at most 2 triangles per side). */
 int32_t ft_create_host_only(ft_context** out);

@@ -466,7 +466,7 @@ def test_tail_kernel_changes_no_pixel_and_no_count(hip, name):
             assert st[key] == stats[0][key], key
 
 
-@pytest.mark.parametrize("name", ["bunny", "moon", "hollow-sphere", "bunny-bsp12", "night-house-det", "repeat", "house"])
+@pytest.mark.parametrize("name", ["bunny", "moon", "hollow-sphere", "bunny-bsp12", "sample-det"])
 def test_pixel_block_classification_changes_no_pixel(hip, name):
     """k_classify finishes 64-pixel blocks that cannot see any object before a single ray is generated: the frame, the hit
     counts and the ray counts must not notice, whole frame or tiles."""

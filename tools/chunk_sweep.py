@@ -8,12 +8,12 @@ sys.path.insert(0, ROOT)
 import functracer_amd as ft  # noqa: E402
 
 ctx = ft.Context(0)
-for name, spp in [("bunny", 16), ("hollow-sphere", 16), ("night-house-det", 16), ("sample-det", 16), ("bunny-bsp12", 16), ("moon", 16)]:
+for name, spp in [("bunny", 16), ("hollow-sphere", 16), ("hollow-sphere", 1), ("night-house-det", 16), ("night-house", 16), ("sample-det", 16), ("bunny-bsp12", 16), ("bunny-full-bsp12", 16), ("moon", 16)]:
     p = ft.parse_scene_file(os.path.join(ROOT, "scenes", name + ".scene"))
     p.lower(ctx)
     jit = ft.jitter_pattern(spp)
     row = []
-    for mi in (2, 4, 8, 16, 32, 64):
+    for mi in (4, 6, 8, 12, 16, 24):
         ctx.set_option("chunk_samples", mi << 20)
         best = 1e9
         for _ in range(4):
