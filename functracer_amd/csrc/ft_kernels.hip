@@ -2,6 +2,7 @@
 //
 // Pipeline per chunk of samples (DESIGN.md §"Kernels"):
 //   k_classify  which 64-pixel blocks can see anything; the rest are finished on the spot (Colour.Zero)
+//   k_compact   the blocks that can, as the frame's active pixel list (in block order)
 //   (primary rays are generated inside bounce 0 of the two kernels below: Image.fs:83-89, 100-110)
 //   k_closest   closest hit         Scene.fs:112-118 over the flattened Scene.intersect (Scene.fs:67-104)
 //   k_shade     Phong + shadow rays + reflection spawn   Shading.fs:24-139
