@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strong", action="store_true", help="keep the frame fixed as ranks are added (strong scaling)")
+    ap.add_argument("--blocking", action="store_true", help="render the timed frames one synchronous ft_render at a time instead of queuing them")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,14 +117,25 @@ def main():
     k_times = {"other": 0.0, "closest": 0.0, "shade": 0.0, "blend": 0.0}   # "other": memsets, k_classify, k_blend, statistics (events bracket k_closest / k_shade only)
     k_launch = dict.fromkeys(k_times, 0)
     st = None
-    for _ in range(args.steps):
-        st = step()
-        rays += st["rays_traced"]
-        kernel_ms += st["kernel_ms"]
-        trace_ms += st["trace_kernel_ms"]
+    if args.blocking:                                              # the reference's own flow: one synchronous frame after the other
+        for _ in range(args.steps):
+            st = step()
+            rays += st["rays_traced"]
+            kernel_ms += st["kernel_ms"]
+            trace_ms += st["trace_kernel_ms"]
+            for k, v in ctx.kernel_times().items():
+                k_times[k] += v["ms"]
+                k_launch[k] += v["launches"]
+    else:                                                          # frames queued back to back (ft_render_enqueue): the host prepares frame
+        for _ in range(args.steps):                                # k+1 while frame k runs; every frame is the same full frame as above
+            ctx.render_enqueue(scene.camera, res_h, res_v, spp, jitter, tiles=bands)
+        st = ctx.wait()                                            # statistics of the last frame; stage times summed over all of them
+        rays = st["rays_traced"] * args.steps
         for k, v in ctx.kernel_times().items():
             k_times[k] += v["ms"]
             k_launch[k] += v["launches"]
+        kernel_ms = sum(k_times.values())
+        trace_ms = k_times["closest"] + k_times["shade"]
     barrier_sync()
     wall = time.perf_counter() - t0
 

@@ -44,6 +44,8 @@ def hip_lib():
         lib.ft_debug_blocked.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, _capi.c_int32_p]
         lib.ft_debug_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.ft_debug_slice.argtypes = [_capi.c_double_p] * 4 + [_capi.c_int32_p, _capi.c_double_p, _capi.c_int32_p]
+        lib.ft_render_enqueue.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32, C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32]
+        lib.ft_render_wait.argtypes = [C.c_void_p, C.POINTER(_capi.ft_stats)]
         lib.ft_get_kernel_times.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_int32_p]
         lib.ft_quantise_rgba8.argtypes = [_capi.c_double_p, C.c_int64, C.POINTER(C.c_uint8)]
         _hip = lib
@@ -221,6 +223,18 @@ class Context(SceneBuilder):
     def fetch_frame(self, out):
         self._check(self._lib.ft_fetch_frame(self._ctx, _capi.dptr(out)))
         return out
+
+    def render_enqueue(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None):
+        """ft_render_enqueue: queue a frame and return; `wait()` retires what is queued."""
+        jitter = np.zeros((1, 2)) if spp == 0 else _capi.as_f64(jitter, (spp, 2))
+        rects, n_rects = _capi.make_rects(tiles)
+        self._check(self._lib.ft_render_enqueue(self._ctx, C.byref(camera), res_h, res_v, spp, _capi.dptr(jitter), max_depth, int(seed), rects, n_rects))
+
+    def wait(self):
+        """ft_render_wait: statistics of the last queued frame; kernel_times() then holds the sums over all frames since the previous wait."""
+        st = _capi.ft_stats()
+        self._check(self._lib.ft_render_wait(self._ctx, C.byref(st)))
+        return st.as_dict()
 
     def kernel_times(self):
         ms = np.zeros(4)

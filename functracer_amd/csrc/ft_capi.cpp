@@ -49,12 +49,23 @@ struct ft_context {
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_hits, d_hit_list, d_touched, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
     int64_t ray_capacity = 0;
-    std::vector<hipEvent_t> events;
-    size_t events_used = 0;
+    // Per-frame host state.  Two slots, so that one frame can be queued while the previous one still runs (ft_render_enqueue).
+    struct FrameSlot {
+        std::vector<hipEvent_t> events; size_t events_used = 0;
+        struct Span { hipEvent_t a, b; int kind; };
+        std::vector<Span> spans;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
+        ftk::RenderCounters* h_rc = nullptr;    // pinned landing place of the frame's statistics
+        bool pending = false;
+        uint64_t rays_primary = 0; int64_t n_pix_total = 0; int32_t spp = 0, n_launches = 0, n_chunks = 0, timing = 1; bool classify = false;
+        std::chrono::steady_clock::time_point wall0;
+    };
+    FrameSlot slots[2];
+    int slot_turn = 0;
+    bool accum_open = false;        // kernel times are being summed over pipelined frames (reset by the next enqueue after a wait)
     // pixel list of the last render, cached across calls with the same resolution and tiles
     std::vector<uint32_t> pixels;
     std::vector<double> jitter_on_device;   // what d_jitter holds
-    ftk::RenderCounters* h_rc = nullptr;    // pinned landing place of the per-render statistics
     std::vector<ft_rect> pixel_rects;
     bool pixels_whole = false, pixels_corner = false;
     DeviceBuf d_out_index;
@@ -117,9 +128,9 @@ int32_t ensure_frame_buffers(ft_context* c, int64_t cap) {
     return FT_OK;
 }
 
-hipEvent_t next_event(ft_context* c) {
-    if (c->events_used == c->events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->events.push_back(e); }
-    return c->events[c->events_used++];
+hipEvent_t next_event(ft_context::FrameSlot& f) {
+    if (f.events_used == f.events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; f.events.push_back(e); }
+    return f.events[f.events_used++];
 }
 
 // ImagePlane.create (Image.fs:48-53, 67-81), evaluated once per frame on the host.
@@ -205,8 +216,7 @@ void ft_destroy(ft_context* c) {
                              &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
-        if (c->h_rc) { (void)hipHostFree(c->h_rc); c->h_rc = nullptr; }
-        for (auto e : c->events) (void)hipEventDestroy(e);
+        for (auto& f : c->slots) { if (f.h_rc) { (void)hipHostFree(f.h_rc); f.h_rc = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -418,7 +428,9 @@ static int32_t fetch_single(ft_context* c, double* out_rgb) {
 
 // ------------------------------------------------------------------------------------------ render
 static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats);
+                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats, bool defer = false);
+static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& f, ft_stats* stats);
+static int32_t retire_pending(ft_context* c, ft_stats* stats);
 
 int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                   int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
@@ -464,7 +476,7 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
 }
 
 static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
+                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats, bool defer) {
     if (!c) return FT_ERR_INVALID;
     if (!cam || res_h < 2 || res_v < 2 || spp < 0 || (spp > 0 && !jitter_xy) || max_depth < 0 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
     if (max_depth > ftk::kMaxBounce) { c->err = "max_depth above 16"; return FT_ERR_UNSUPPORTED; }
@@ -550,8 +562,8 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
     else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
     if (jit != c->jitter_on_device) {                              // frames usually reuse the pattern: skip the staged host-to-device copy
-        if ((rc = upload(c, c->d_jitter, jit)) != FT_OK) return rc;
-        c->jitter_on_device = jit;
+        c->jitter_on_device = jit;                                 // (the copy source outlives this call)
+        if ((rc = upload(c, c->d_jitter, c->jitter_on_device)) != FT_OK) return rc;
     }
     FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 2), c->stream));
 
@@ -584,25 +596,30 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     auto* cc = c->d_cc.as<ftk::ChunkCounters>();
     auto* rcount = c->d_rc.as<ftk::RenderCounters>();
 
-    c->events_used = 0;
-    struct Span { hipEvent_t a, b; int kind; };
-    std::vector<Span> spans;
+    // A blocking call retires whatever is in flight first; a deferred one only the frame whose slot it is about to reuse.
+    if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
+    ft_context::FrameSlot& F = c->slots[c->slot_turn];
+    if (F.pending) { int32_t prc = retire_frame(c, F, nullptr); if (prc != FT_OK) return prc; }
+    if (defer && !c->accum_open) { for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = true; }
+    F.events_used = 0; F.spans.clear();
+    auto& spans = F.spans;
+    using Span = ft_context::FrameSlot::Span;
     // HIP events between stages.  An event between two dependent kernels costs about 6 us of stream time (measured: 0.2 us
     // between k_classify and k_classify_finish, which have none between them), so by default ("timing" = 1) only the two
     // kernels that matter, k_closest and k_shade, are bracketed; 2 brackets every stage, 0 only the frame.
-    hipEvent_t ev0 = next_event(c), ev1 = nullptr;
+    hipEvent_t ev0 = next_event(F), ev1 = nullptr;
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     hipEvent_t boundary = ev0;
     bool boundary_fresh = true;                                    // `boundary` was recorded right before the next launch
     const int timing = c->timing;
     auto timed = [&](int kind, auto&& fn) {
         const bool bracket = timing >= 2 || (timing == 1 && (kind == 1 || kind == 2));
-        if (bracket && !boundary_fresh) { boundary = next_event(c); if (boundary) (void)hipEventRecord(boundary, c->stream); }
+        if (bracket && !boundary_fresh) { boundary = next_event(F); if (boundary) (void)hipEventRecord(boundary, c->stream); }
         fn();
         if (!bracket) { boundary_fresh = false; return; }
-        hipEvent_t b = next_event(c);
+        hipEvent_t b = next_event(F);
         if (b) (void)hipEventRecord(b, c->stream);
-        if (boundary && b) spans.push_back({boundary, b, kind});
+        if (boundary && b) spans.push_back(Span{boundary, b, kind});
         boundary = b; boundary_fresh = true;
     };
     int n_chunks = 0, n_launches = 0;
@@ -645,30 +662,48 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     }
     timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, ftk::kStatSlots); });
     if (boundary_fresh) ev1 = boundary;
-    else { ev1 = next_event(c); if (ev1) (void)hipEventRecord(ev1, c->stream); }
+    else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
     FT_HIP(c, hipGetLastError());
-    if (!c->h_rc) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rc), sizeof(ftk::RenderCounters), hipHostMallocDefault));
-    FT_HIP(c, hipMemcpyAsync(c->h_rc, c->d_rc.p, sizeof(ftk::RenderCounters), hipMemcpyDeviceToHost, c->stream));   // rides the same wait
-    FT_HIP(c, hipStreamSynchronize(c->stream));
-
-    const ftk::RenderCounters hrc = *c->h_rc;
+    if (!F.h_rc) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_rc), sizeof(ftk::RenderCounters), hipHostMallocDefault));
+    FT_HIP(c, hipMemcpyAsync(F.h_rc, c->d_rc.p, sizeof(ftk::RenderCounters), hipMemcpyDeviceToHost, c->stream));   // rides the frame's one wait
+    F.done = next_event(F);
+    if (F.done) FT_HIP(c, hipEventRecord(F.done, c->stream));
+    F.ev0 = ev0; F.ev1 = ev1; F.pending = true; F.wall0 = wall0; F.timing = timing;
+    F.rays_primary = 0; for (auto& j : jobs) F.rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;
+    F.n_pix_total = n_pix_total; F.spp = spp; F.n_launches = n_launches; F.n_chunks = n_chunks; F.classify = classify;
     c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v;
+    c->slot_turn ^= 1;
+    if (defer) return FT_OK;                                       // ft_render_enqueue: the frame is retired by a later call
+    int32_t rrc = retire_frame(c, F, stats);
+    if (rrc != FT_OK) return rrc;
     if (out_rgb) { int32_t frc = fetch_single(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
-    for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
-    for (auto& s : spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; } }
+    return FT_OK;
+}
+
+// Wait for a queued frame, add its stage times to the context's sums and fill its statistics.
+static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* stats) {
+    if (!F.pending) return FT_OK;
+    F.pending = false;
+    if (F.done) FT_HIP(c, hipEventSynchronize(F.done)); else FT_HIP(c, hipStreamSynchronize(c->stream));
+    const ftk::RenderCounters hrc = *F.h_rc;
+    const int timing = F.timing; const int32_t spp = F.spp; const int64_t n_pix_total = F.n_pix_total; const bool classify = F.classify;
+    hipEvent_t ev0 = F.ev0, ev1 = F.ev1;
+    double k1 = 0.0, k2 = 0.0;
+    for (auto& s : F.spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; if (s.kind == 1) k1 += ms; if (s.kind == 2) k2 += ms; } }
     if (timing < 2) {                                              // index 0 = everything that was not bracketed (memsets, k_classify, k_blend, statistics)
         float total = 0; if (ev0 && ev1) (void)hipEventElapsedTime(&total, ev0, ev1);
-        c->k_ms[0] = std::max(0.0, (double)total - c->k_ms[1] - c->k_ms[2]); c->k_ms[3] = 0.0;
+        c->k_ms[0] += std::max(0.0, (double)total - k1 - k2);
     }
     if (stats) {
+        std::memset(stats, 0, sizeof *stats);
         float ms = 0;
         if (ev0 && ev1) (void)hipEventElapsedTime(&ms, ev0, ev1);
-        stats->rays_primary = 0; for (auto& j : jobs) stats->rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;
+        stats->rays_primary = F.rays_primary;
         stats->rays_shadow = hrc.rays_shadow; stats->rays_reflect = hrc.rays_reflect;
         stats->rays_traced = stats->rays_primary + stats->rays_shadow + stats->rays_reflect;
         stats->rays_reference_equivalent = (double)stats->rays_primary + hrc.ref_equiv;
         stats->hits_primary = hrc.hits_primary; stats->csg_overflow = hrc.csg_overflow;
-        stats->kernel_ms = ms; stats->trace_kernel_ms = c->k_ms[1] + c->k_ms[2];
+        stats->kernel_ms = ms; stats->trace_kernel_ms = k1 + k2;
         {   // bytes the pipeline has to move by construction (ft_device.h); P primary rays, R reflection rays, H hits, H0 primary hits
             // rays and hits that k_tail handled never became records: Ti rays were handed to it (written once, read once), Tr spawned and Th shaded inside it
             const uint64_t Pc = (uint64_t)hrc.pixels_culled * (uint64_t)spp, P = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, Pc), Ti = hrc.tail_in, Tr = hrc.tail_rays, Th = hrc.tail_hits, RR = hrc.rays_reflect, HH = hrc.hits_total;
@@ -685,14 +720,41 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
                                        P * ftk::kTouchedBytes + H0 * ftk::kAccBytes + 24ull * (uint64_t)n_pix_total +   // + k_blend (and the pixels k_classify wrote)
                                        (classify ? (uint64_t)n_pix_total * ftk::kPixelIdBytes + (P / (uint64_t)spp) * 2 * ftk::kPixelIdBytes : 0ull);   // + k_classify
         }
-        stats->n_launches = n_launches; stats->n_chunks = n_chunks;
-        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        stats->n_launches = F.n_launches; stats->n_chunks = F.n_chunks;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - F.wall0).count();
     }
     if (hrc.csg_overflow) {
         c->err = "CSG hit list overflow on " + std::to_string(hrc.csg_overflow) + " rays: raise csg_mesh_capacity (ft_set_option)";
         return FT_ERR_OVERFLOW;
     }
     return FT_OK;
+}
+
+// Retire every queued frame, oldest first; `stats` receives the newest one's.
+static int32_t retire_pending(ft_context* c, ft_stats* stats) {
+    ft_context::FrameSlot& older = c->slots[c->slot_turn];
+    ft_context::FrameSlot& newer = c->slots[c->slot_turn ^ 1];
+    int32_t rc = FT_OK;
+    if (older.pending) { int32_t r = retire_frame(c, older, newer.pending ? nullptr : stats); if (r != FT_OK) rc = r; }
+    if (newer.pending) { int32_t r = retire_frame(c, newer, stats); if (r != FT_OK) rc = r; }
+    return rc;
+}
+
+/* Pipelined rendering (one device): queue the frame and return; see functracer_hip.h. */
+int32_t ft_render_enqueue(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                          int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles) {
+    if (!c) return FT_ERR_INVALID;
+    if (!c->peers.empty()) { c->err = "ft_render_enqueue works on a one-device context"; return FT_ERR_UNSUPPORTED; }
+    return render_single(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, nullptr, nullptr, true);
+}
+int32_t ft_render_wait(ft_context* c, ft_stats* stats) {
+    if (!c) return FT_ERR_INVALID;
+    if (c->host_only) return FT_ERR_NO_DEVICE;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    FT_HIP(c, hipSetDevice(c->device));
+    int32_t rc = retire_pending(c, stats);
+    c->accum_open = false;
+    return rc;
 }
 
 int32_t ft_get_kernel_times(ft_context* c, double ms[4], int32_t launches[4]) {

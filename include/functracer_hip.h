@@ -190,6 +190,16 @@ int32_t ft_render(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t 
 
 int32_t ft_fetch_frame(ft_context* ctx, double* out_rgb);
 
+/* Pipelined rendering on a one-device context, for hosts that render frame after frame (an animation, a progressive preview):
+ * ft_render_enqueue queues a frame exactly as ft_render(out_rgb = NULL) would and returns without waiting, so the host prepares
+ * the next frame while this one runs; at most two frames are in flight (queuing a third first waits for the oldest).
+ * ft_render_wait blocks until everything queued has finished, reports the statistics of the LAST frame, and leaves in
+ * ft_get_kernel_times the stage times and launch counts summed over all frames since the previous wait.  The frame buffer holds
+ * the last frame (ft_fetch_frame).  The reference's own flow is synchronous (Program.fs:63-64): ft_render stays that way. */
+int32_t ft_render_enqueue(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                          int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles);
+int32_t ft_render_wait(ft_context* ctx, ft_stats* stats);
+
 /* Closest hit of single rays through the device path (Scene.intersectScene, Scene.fs:118, after
  * Shading.slightOffset is NOT applied): for tests.  Outputs per ray: t, p[3], n[3], material index
  * resolved colour[3]; hit[i] = 0 when the ray misses. */

@@ -562,3 +562,25 @@ def test_coincident_items_resolve_ties_in_scene_order(hip):
     want_f, _ = orc.render(cam, 128, 96, 1, jit)
     got_f, _ = hip.render(cam, 128, 96, 1, jit)
     assert H.assert_frames_match(got_f, want_f, what="coincident spheres") < 1e-9
+
+
+def test_pipelined_frames_equal_blocking_frames(hip):
+    """ft_render_enqueue / ft_render_wait: frames queued back to back, each equal to its blocking twin; the wait reports the
+    last frame's statistics and the stage times summed over the queued frames."""
+    p = _load("hollow-sphere")
+    p.lower(hip)
+    jit = ft.jitter_pattern(2)
+    cams = [ft.make_camera((5.7 - 0.4 * k, 5.7, -5.7), (0, 0, 4), (0, 1, 0), H.deg(60.0)) for k in range(4)]
+    blocking = [hip.render(c, 160, 96, 2, jit) for c in cams]
+    per_frame_launches = hip.kernel_times()["closest"]["launches"]
+    for c in cams[:3]:
+        hip.render_enqueue(c, 160, 96, 2, jit)
+    st = hip.wait()
+    assert np.array_equal(hip.fetch_frame(np.zeros((96, 160, 3))), blocking[2][0])
+    for key in ("rays_traced", "rays_shadow", "rays_reflect", "hits_primary", "rays_reference_equivalent"):
+        assert st[key] == blocking[2][1][key], key
+    assert hip.kernel_times()["closest"]["launches"] == 3 * per_frame_launches
+    hip.render_enqueue(cams[3], 160, 96, 2, jit)                  # a blocking call retires what is in flight first
+    img, st2 = hip.render(cams[0], 160, 96, 2, jit)
+    assert np.array_equal(img, blocking[0][0]) and st2["rays_traced"] == blocking[0][1]["rays_traced"]
+    assert hip.wait()["rays_traced"] == 0                         # nothing queued
