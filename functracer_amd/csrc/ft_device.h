@@ -50,8 +50,8 @@ constexpr uint64_t kRayRecBytes = 60, kHitRecBytes = 16;
 // read once; an accumulator 24 B stored (bounce 0) or read-modify-written (later bounces); a pixel 24 B out.
 constexpr uint64_t kPixelIdBytes = 4, kTouchedBytes = 1, kListBytes = 4, kAccBytes = 24;
 
-// Pixels of a chunk that are actually traced (k_classify): count and its reciprocal (division-free index arithmetic).
-struct PixCount { uint32_t n_pix, pad; double inv_n_pix; };
+// Length of the frame's active pixel list (k_classify / k_compact), in device memory: the later stages size themselves from it.
+struct PixCount { uint32_t n_pix, pad[3]; };
 // Per-chunk device counters (zeroed before every chunk).
 struct ChunkCounters {
     uint32_t n_rays[kMaxBounce + 2];   // rays queued for bounce k

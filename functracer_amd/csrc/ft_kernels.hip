@@ -1123,6 +1123,7 @@ struct ClosestArgs {
     uint32_t* hit_list; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc; int32_t bounce; uint32_t tail_threshold;
 };
 
+// Resident blocks per CU the compiler must leave room for (measured: 3, 5, 6 are slower - spills or too few waves).
 #ifndef FT_CLOSEST_BLOCKS
 #define FT_CLOSEST_BLOCKS 4
 #endif
