@@ -156,7 +156,20 @@ ftk::Camera make_camera(const ft_camera& cam, int res_h, int res_v) {
     return out;
 }
 
-size_t lds_bytes_for(const fth::FlatScene& f) { return (size_t)(4 * f.csg_capacity + f.stack_capacity) * ftk::kBlock * 4; }
+// LDS per workgroup: the per-lane CSG hit lists (4 words per entry) and tree stacks.  When the lists alone would not fit, lanes are
+// folded (ft_kernels.hip, HitList): fold live lanes share the columns of 64 lanes, so a column needs only ceil(capacity / fold) rows.
+constexpr size_t kLdsPerWorkgroup = 160 * 1024;
+int lane_fold_for(const fth::FlatScene& f) {
+    for (int fold = 1; fold <= 16; fold *= 2) {
+        const size_t rows = ((size_t)f.csg_capacity + (size_t)fold - 1) / (size_t)fold;
+        if ((4 * rows + (size_t)f.stack_capacity) * ftk::kBlock * 4 <= kLdsPerWorkgroup) return fold;
+    }
+    return 0;
+}
+size_t lds_bytes_for(const fth::FlatScene& f) {
+    const int fold = std::max(1, lane_fold_for(f));
+    return (4 * (((size_t)f.csg_capacity + (size_t)fold - 1) / (size_t)fold) + (size_t)f.stack_capacity) * ftk::kBlock * 4;
+}
 
 } // namespace
 
@@ -352,7 +365,7 @@ static int32_t upload_scene(ft_context* c) {
     int32_t rc;
     FT_HIP(c, hipSetDevice(c->device));
     const fth::FlatScene& f = c->flat;
-    if (lds_bytes_for(f) > 160 * 1024) { c->err = "scene needs more than 160 KiB of LDS per workgroup for CSG lists / BSP stacks"; return FT_ERR_UNSUPPORTED; }
+    if (lane_fold_for(f) == 0) { c->err = "scene needs more than 160 KiB of LDS per workgroup for CSG lists / BSP stacks even with 4 live lanes per wave"; return FT_ERR_UNSUPPORTED; }
     if ((rc = upload(c, c->d_leaves, f.leaves)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_m2w, f.m2w)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_materials, f.materials)) != FT_OK) return rc;
@@ -388,6 +401,7 @@ static int32_t upload_scene(ft_context* c) {
     S.n_items = (int32_t)f.item_pc.size() - 1; S.n_cull_rows = f.cull_bundle ? (int32_t)(f.cull_rows.size() / 3) : -1;
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
+    S.lane_fold = lane_fold_for(f); S.csg_rows = (f.csg_capacity + S.lane_fold - 1) / S.lane_fold;
     S.shadow_rays_per_hit = 0;
     for (auto& l : f.lights) S.shadow_rays_per_hit += (l.kind == ftd::LT_SOFT) ? l.samples : 1;   // Shading.fs:24-42
     c->committed = true;

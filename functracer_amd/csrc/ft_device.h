@@ -36,6 +36,7 @@ struct DevScene {
     int32_t n_leaves, n_lights, csg_cap, stack_cap;
     int32_t shadow_rays_per_hit;   // sum over lights of the shadow rays the reference casts per hit
     int32_t n_items, n_cull_rows;  // n_cull_rows < 0: pre-test disabled
+    int32_t csg_rows, lane_fold;   // LDS rows per hit-list column and lanes folded together (see HitList): csg_cap <= csg_rows * lane_fold
     int32_t coherent_waves;        // 1 (default): bounce-0 wavefronts use the bundle paths (cone cull, packet traversal); 0: every wave is treated as incoherent (diagnostic)   // sum over lights of the shadow rays the reference casts per hit
 };
 

@@ -92,7 +92,7 @@ struct Scene {
     const float* coarse_boxes;   // lane k reads box k
     cdp cull_rows;
     cup item_pc;
-    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows;
+    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold;
 };
 static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
 template <class DS> FT_DEV Scene scene_view(const DS& g) {
@@ -104,7 +104,7 @@ template <class DS> FT_DEV Scene scene_view(const DS& g) {
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig); s.wide = to_const_as(g.wide); s.mesh_wide = to_const_as(g.mesh_wide);
     s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.coarse_boxes = g.coarse_boxes; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
-    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap;
+    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap; s.csg_rows = g.csg_rows; s.lane_fold = g.lane_fold;
     return s;
 }
 struct MaterialV { double colour[3]; double roughness, reflectance, shineyness; uint32_t apply_lighting; int32_t texture; uint32_t hue_rot; };
@@ -150,22 +150,30 @@ struct HitList {
     uint32_t* base;
     int len;
     int cap;
+    int rows, stride;                                               // lane folding (below): LDS rows per column, lanes between a lane's columns
     unsigned long long marks_lo, marks_hi;
     bool overflow;
 
-    FT_DEV void init(uint32_t* lds, int capacity) { base = lds + threadIdx.x; len = 0; cap = capacity; marks_lo = marks_hi = 0; overflow = false; }
+    // Lane folding: a scene whose lists need more LDS than a workgroup has (meshes under CSG) runs with 64 / fold live lanes per
+    // wave, and live lane l also owns the columns of the idle lanes l + 64/fold, l + 2*64/fold, ...: entry e lives in row
+    // e mod rows of column e / rows.  fold = 1 (the rule): rows = cap and the column never changes.
+    FT_DEV void init(uint32_t* lds, int capacity, int rows_per_column, int fold) {
+        base = lds + threadIdx.x; len = 0; cap = capacity; rows = rows_per_column; stride = 64 / fold; marks_lo = marks_hi = 0; overflow = false;
+    }
+    FT_DEV uint32_t* at(int e) const { int col = 0; while (e >= rows) { e -= rows; col += stride; } return base + (e * 4) * kBlock + col; }
     FT_DEV void store(int e, double t, uint32_t id0, uint32_t id1) {
         unsigned long long b = __double_as_longlong(t);
-        base[(e * 4 + 0) * kBlock] = (uint32_t)b; base[(e * 4 + 1) * kBlock] = (uint32_t)(b >> 32);
-        base[(e * 4 + 2) * kBlock] = id0; base[(e * 4 + 3) * kBlock] = id1;
+        uint32_t* p = at(e);
+        p[0] = (uint32_t)b; p[kBlock] = (uint32_t)(b >> 32); p[2 * kBlock] = id0; p[3 * kBlock] = id1;
     }
     FT_DEV double t_of(int e) const {
-        unsigned long long b = (unsigned long long)base[(e * 4 + 0) * kBlock] | ((unsigned long long)base[(e * 4 + 1) * kBlock] << 32);
+        const uint32_t* p = at(e);
+        unsigned long long b = (unsigned long long)p[0] | ((unsigned long long)p[kBlock] << 32);
         return __longlong_as_double(b);
     }
-    FT_DEV uint32_t id0_of(int e) const { return base[(e * 4 + 2) * kBlock]; }
-    FT_DEV uint32_t id1_of(int e) const { return base[(e * 4 + 3) * kBlock]; }
-    FT_DEV void set_id0(int e, uint32_t v) { base[(e * 4 + 2) * kBlock] = v; }
+    FT_DEV uint32_t id0_of(int e) const { return at(e)[2 * kBlock]; }
+    FT_DEV uint32_t id1_of(int e) const { return at(e)[3 * kBlock]; }
+    FT_DEV void set_id0(int e, uint32_t v) { at(e)[2 * kBlock] = v; }
     FT_DEV void push(double t, uint32_t id0, uint32_t id1) {
         if (len < cap) { store(len, t, id0, id1); ++len; } else overflow = true;   // never silently dropped: reported via RenderCounters
     }
@@ -751,8 +759,8 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
 template <bool ANY, bool MESH>
 FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow, bool coherent = false) {
     HitList L;
-    L.init(lds, S.csg_cap);
-    int32_t* stack = reinterpret_cast<int32_t*>(lds + 4 * S.csg_cap * kBlock) + threadIdx.x;
+    L.init(lds, S.csg_cap, S.csg_rows, S.lane_fold);
+    int32_t* stack = reinterpret_cast<int32_t*>(lds + 4 * S.csg_rows * kBlock) + threadIdx.x;
     // Coherent waves visit only the top-level items their ray bundle can reach (ascending, so ties between items still
     // go to the earlier one); everything else walks the whole program, every item behind its own OP_CULL.
     ItemMask IM{~0ull, ~0ull, false};
@@ -1019,9 +1027,9 @@ struct BatchCursor {
 // Rays per batch: a wave's cost grows with the number of DISTINCT scene items its rays touch, so when a launch has
 // fewer rays than the grid has lanes (late bounces: a few hundred incoherent reflection rays), the rays are spread
 // thinly — 32, 16, ... 1 per wave — over the otherwise idle waves instead of packing 64 unrelated rays into one.
-FT_DEV uint32_t batch_lanes_for(uint32_t n) {
+FT_DEV uint32_t batch_lanes_for(uint32_t n, int lane_fold) {
     const uint32_t waves = gridDim.x * (kBlock / 64);
-    uint32_t b = 64u;
+    uint32_t b = 64u / (uint32_t)lane_fold;                         // folded lanes lend their LDS columns to the live ones (HitList)
     while (b > 1u && n < b * waves) b >>= 1;
     return b;
 }
@@ -1138,7 +1146,7 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
     const uint32_t n_pix = px.n;
     const uint32_t n = bounce == 0 ? n_pix * (uint32_t)K->gen.spp : cc->n_rays[bounce];
     if (bounce > 0 && n < K->tail_threshold) return;               // few rays left: k_tail follows them to the end (nothing is spawned after this bounce)
-    const uint32_t B = batch_lanes_for(n);
+    const uint32_t B = batch_lanes_for(n, S.lane_fold);
     const uint32_t n_batches = (n + B - 1) / B;
     unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
     // Compaction of the rays that hit (wave ballot + prefix sum): hit masks of up to 48 batches are parked in the
@@ -1353,7 +1361,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
     const Pix px = pix_count(&K->gen);                              // once per launch: the count sits two dependent loads away
     const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
-    const uint32_t B = batch_lanes_for(n);
+    const uint32_t B = batch_lanes_for(n, S.lane_fold);
     const uint32_t n_batches = (n + B - 1) / B;
     BatchCursor cursor(&cc->work_shade[bounce][0]);
     for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
@@ -1647,7 +1655,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(Tai
     const int n_lights = S.n_lights;
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0, n_in_wave = 0;
     double ref_wave = 0.0;
-    const uint32_t B = batch_lanes_for(n);
+    const uint32_t B = batch_lanes_for(n, S.lane_fold);
     const uint32_t n_batches = (n + B - 1) / B;
     BatchCursor cursor(&cc->work_trace[kMaxBounce + 1][0]);       // a cursor row no bounce uses
     for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
@@ -1774,11 +1782,11 @@ __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene Sg, const dou
                                                            int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
-    const uint32_t n_batches = (n + 63) / 64;
+    const uint32_t B = 64u / (uint32_t)S.lane_fold, n_batches = (n + B - 1) / B;
     for (uint32_t b = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; b < n_batches; b += gridDim.x * (kBlock / 64)) {
-        const uint32_t i = b * 64 + lane_id();
+        const uint32_t i = b * B + lane_id();
         Query<false> q;
-        q.active = i < n; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0; q.blocked = false;
+        q.active = i < n && lane_id() < B; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0; q.blocked = false;
         Ray r{0, 0, 0, 0, 0, 0};
         if (q.active) r = {o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]};
         bool overflow;
@@ -1802,11 +1810,11 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
                                                            const double* __restrict__ max_dist, uint32_t n, int32_t* blocked, RenderCounters* rc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
-    const uint32_t n_batches = (n + 63) / 64;
+    const uint32_t B = 64u / (uint32_t)S.lane_fold, n_batches = (n + B - 1) / B;
     for (uint32_t b = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; b < n_batches; b += gridDim.x * (kBlock / 64)) {
-        const uint32_t i = b * 64 + lane_id();
+        const uint32_t i = b * B + lane_id();
         Query<true> q;
-        q.active = i < n; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0; q.max_dist = 0;
+        q.active = i < n && lane_id() < B; q.blocked = false; q.best_t = 0; q.id0 = 0; q.id1 = 0; q.max_dist = 0;
         Ray r{0, 0, 0, 0, 0, 0};
         if (q.active) { r = {o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]}; q.max_dist = max_dist[i]; }
         bool overflow;

@@ -584,3 +584,32 @@ def test_pipelined_frames_equal_blocking_frames(hip):
     img, st2 = hip.render(cams[0], 160, 96, 2, jit)
     assert np.array_equal(img, blocking[0][0]) and st2["rays_traced"] == blocking[0][1]["rays_traced"]
     assert hip.wait()["rays_traced"] == 0                         # nothing queued
+
+
+def test_hit_lists_larger_than_the_lds_fold_lanes(hip):
+    """Two meshes under nested CSG at a capacity of 48 hits each: 100+ list entries per lane, 400 KiB for 256 lanes - more LDS than
+    a workgroup has.  The scene then runs with fewer live lanes per wave, each owning several lanes' columns (HitList)."""
+    tris = np.asarray(_bunny_tris()).reshape(-1, 9)
+    orc = O.Oracle()
+    hip.set_option("csg_mesh_capacity", 48)
+    try:
+        for b in (orc, hip):
+            b.clear()
+            m1 = b.scale(7.0, b.bsp_mesh(0, tris))
+            m2 = b.translate((0.25, 0.1, 0.0), b.scale(7.0, b.bsp_mesh(2, tris)))
+            node = b.subtract(b.union(m1, b.translate((0.1, 0.9, 0.0), b.scale(0.4, b.primitive(ft.SPHERE)))), m2)
+            b.set_objects(b.group([b.material(node, colour=(0.8, 0.5, 0.3), reflectance=0.3, shineyness=10), b.translate((0, -0.2, 0), b.primitive(ft.PLANE))]))
+            b.add_directional((-1, -2, 1.5), (1, 1, 1))
+            b.commit()
+        assert hip.scene_info()["csg_capacity"] * 16 * 256 > 160 * 1024          # really beyond one workgroup's LDS
+        o, d = H.random_rays(6000, seed=3, origin_scale=2.5, toward=(0, 0.8, 0), spread=1.0)
+        H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="folded lanes")
+        md = np.abs(np.random.default_rng(8).normal(size=o.shape[0])) * 5.0
+        assert np.array_equal(hip.blocked(o, d, md), orc.blocked(o, d, md))
+        cam = ft.make_camera((0.5, 1.2, -3.0), (0, 0.8, 0), (0, 1, 0), H.deg(50.0))
+        jit = ft.jitter_pattern(2)
+        want, ost = orc.render(cam, 96, 64, 2, jit)
+        got, st = hip.render(cam, 96, 64, 2, jit)
+        assert H.assert_frames_match(got, want, what="folded lanes") < 1e-6 and st["rays_reference_equivalent"] == ost["rays_traced"]
+    finally:
+        hip.set_option("csg_mesh_capacity", 32)
