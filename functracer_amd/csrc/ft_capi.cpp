@@ -429,6 +429,7 @@ int32_t ft_fetch_frame(ft_context* c, double* out_rgb) {
 static int32_t fetch_single(ft_context* c, double* out_rgb) {
     if (c->last_n_pix <= 0) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
     FT_HIP(c, hipSetDevice(c->device));
+    FT_HIP(c, hipStreamSynchronize(c->stream));                     // frames queued with ft_render_enqueue may still be running (the stream is non-blocking)
     const int64_t n = c->last_n_pix;
     if (c->pixels_whole) {                                         // k_blend wrote the frame in place
         FT_HIP(c, hipMemcpy(out_rgb, c->d_out.p, (size_t)c->last_res_h * c->last_res_v * 24, hipMemcpyDeviceToHost));
