@@ -62,6 +62,7 @@ struct ft_context {
     };
     FrameSlot slots[2];
     int slot_turn = 0;
+    bool csg_auto_grow = true;   // ft_render: double csg_mesh_capacity and render again when a hit list overflows
     bool accum_open = false;        // kernel times are being summed over pipelined frames (reset by the next enqueue after a wait)
     // pixel list of the last render, cached across calls with the same resolution and tiles
     std::vector<uint32_t> pixels;
@@ -244,6 +245,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "coherent_waves")) { c->coherent_waves = value != 0; c->dev_scene.coherent_waves = value != 0 ? 1 : 0; for (ft_context* p : c->peers) { p->coherent_waves = value != 0; p->dev_scene.coherent_waves = c->dev_scene.coherent_waves; } return FT_OK; }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
+    if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
     if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
@@ -447,9 +449,33 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
 static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& f, ft_stats* stats);
 static int32_t retire_pending(ft_context* c, ft_stats* stats);
 
+static int32_t render_frame(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                            int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats);
+
+// The reference's hit lists are unbounded F# lists; the device's are sized at commit time.  A line that crosses a mesh under CSG
+// more often than "csg_mesh_capacity" allows is detected (never truncated): the blocking call then doubles the capacity,
+// re-commits the scene and renders the frame again, so the caller sees the reference's result without tuning anything.  The
+// larger capacity stays for the following frames.  Only when the lists stop fitting is FT_ERR_OVERFLOW handed to the caller.
 int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                   int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
     if (!c) return FT_ERR_INVALID;
+    int32_t rc = render_frame(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats);
+    while (rc == FT_ERR_OVERFLOW && c->csg_auto_grow && c->graph.csg_mesh_capacity < 255) {
+        const int32_t before = c->graph.csg_mesh_capacity;
+        const std::string why = c->err;
+        c->graph.csg_mesh_capacity = std::min(255, before * 2);
+        if (ft_scene_commit(c) != FT_OK) {                          // the longer lists do not fit: back to the scene as it was
+            c->graph.csg_mesh_capacity = before;
+            if (ft_scene_commit(c) == FT_OK) c->err = why;
+            return FT_ERR_OVERFLOW;
+        }
+        rc = render_frame(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats);
+    }
+    return rc;
+}
+
+static int32_t render_frame(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                            int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
     if (c->peers.empty() || c->host_only) return render_single(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats);
     if (!cam || res_h < 2 || res_v < 2 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
     if (!c->committed) { c->err = "scene not committed (ft_scene_commit)"; return FT_ERR_STATE; }

@@ -586,6 +586,45 @@ def test_pipelined_frames_equal_blocking_frames(hip):
     assert hip.wait()["rays_traced"] == 0                         # nothing queued
 
 
+def test_overflowing_hit_lists_grow_and_the_frame_still_matches(hip):
+    """A mesh under CSG at a capacity of 2 hits: most lines through the bunny cross it more often.  The blocking call doubles the
+    capacity until the lists hold every hit and delivers the oracle's frame; with "csg_auto_grow" off the same frame is refused
+    loudly (FT_ERR_OVERFLOW) - a hit is never dropped silently."""
+    from functracer_amd._capi import FtError
+    tris = np.asarray(_bunny_tris()).reshape(-1, 9)
+    orc = O.Oracle()
+    cam = ft.make_camera((0, 1, -6), (0, 0.6, 0), (0, 1, 0), H.deg(40.0))
+    jit = ft.jitter_pattern(1)
+
+    def build(b):
+        b.clear()
+        m = b.scale(7.0, b.bsp_mesh(3, tris))
+        node = b.subtract(m, b.translate((0.0, 0.9, -0.3), b.scale(0.5, b.primitive(ft.SPHERE))))
+        b.set_objects(b.group([b.material(node, colour=(0.8, 0.5, 0.3), reflectance=0.2, shineyness=10)]))
+        b.add_directional((-1, -1, 1), (1, 1, 1))
+        b.commit()
+
+    try:
+        hip.set_option("csg_mesh_capacity", 2)
+        hip.set_option("csg_auto_grow", 0)
+        build(hip)
+        small = hip.scene_info()["csg_capacity"]
+        with pytest.raises(FtError, match="OVERFLOW"):
+            hip.render(cam, 96, 64, 1, jit)
+        hip.set_option("csg_auto_grow", 1)
+        build(orc)
+        want, ost = orc.render(cam, 96, 64, 1, jit)
+        got, st = hip.render(cam, 96, 64, 1, jit)
+        assert H.assert_frames_match(got, want, what="grown hit lists") < 1e-9
+        assert st["rays_reference_equivalent"] == ost["rays_traced"] and st["csg_overflow"] == 0
+        assert hip.scene_info()["csg_capacity"] > small           # and the larger lists stay for the next frame
+        again, _ = hip.render(cam, 96, 64, 1, jit)
+        assert np.array_equal(again, got)
+    finally:
+        hip.set_option("csg_auto_grow", 1)
+        hip.set_option("csg_mesh_capacity", 32)
+
+
 def test_hit_lists_larger_than_the_lds_fold_lanes(hip):
     """Two meshes under nested CSG at a capacity of 48 hits each: 100+ list entries per lane, 400 KiB for 256 lanes - more LDS than
     a workgroup has.  The scene then runs with fewer live lanes per wave, each owning several lanes' columns (HitList)."""
