@@ -19,7 +19,7 @@ __all__ = ["Context", "ParsedScene", "parse_scene", "parse_scene_file", "jitter_
            "parse_colour", "parse_ply", "FtError", "make_camera", "HIP_LIB", "HOST_LIB", "DEFAULT_SEED"]
 
 HIP_LIB = os.environ.get("FT_HIP_LIB") or os.path.join(_capi.LIB_DIR, "libfunctracer_hip.so")   # FT_HIP_LIB: experimental builds
-HOST_LIB = os.path.join(_capi.LIB_DIR, "libfunctracer_host.so")
+HOST_LIB = os.environ.get("FT_HOST_LIB") or os.path.join(_capi.LIB_DIR, "libfunctracer_host.so")
 DEFAULT_SEED = 20260104          # jitter pattern seed of the BASELINE configs
 MAX_DEPTH = 8                    # Shading.fs:142
 

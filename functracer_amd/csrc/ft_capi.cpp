@@ -882,7 +882,8 @@ int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9
     int32_t rc = fth::slice_triangle(p0, n, tri, a, b, err);
     if (rc != FT_OK) return rc;
     *n_above = (int32_t)(a.size() / 9); *n_below = (int32_t)(b.size() / 9);
-    std::memcpy(above, a.data(), a.size() * 8); std::memcpy(below, b.data(), b.size() * 8);
+    if (!a.empty()) std::memcpy(above, a.data(), a.size() * 8);
+    if (!b.empty()) std::memcpy(below, b.data(), b.size() * 8);
     return FT_OK;
 }
 

@@ -130,9 +130,9 @@ bool decodePnm(const std::vector<uint8_t>& f, int& w, int& h, std::vector<uint8_
 
 bool loadImageRgb24(const std::string& path, int& width, int& height, std::vector<uint8_t>& rgb, std::string& err) {
     if (path.rfind("http://", 0) == 0 || path.rfind("https://", 0) == 0) { err = "image texture: URLs cannot be fetched (Textures/Image.fs:11-13 uses HTTP; no network here): " + path; return false; }
-    std::ifstream in(path, std::ios::binary);
-    if (!in) { err = "cannot open image file: " + path; return false; }
-    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    std::string bytes;
+    if (!readWholeFile(path, bytes)) { err = "cannot open image file: " + path; return false; }
+    std::vector<uint8_t> f(bytes.begin(), bytes.end());
     static const uint8_t png_magic[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
     if (f.size() > 8 && !std::memcmp(f.data(), png_magic, 8)) return decodePng(f, width, height, rgb, err);
     if (f.size() > 2 && f[0] == 'P' && (f[1] == '2' || f[1] == '3' || f[1] == '5' || f[1] == '6')) return decodePnm(f, width, height, rgb, err);

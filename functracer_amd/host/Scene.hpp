@@ -107,6 +107,8 @@ bool parseScene(const std::string& text, const std::string& baseDir, SceneOption
 // PlyParser.parse (PlyParser.fs:65-69).
 bool parsePly(const std::string& text, std::vector<Triangle>& triangles, std::string& error);
 // Image.Load<Rgb24> (Textures/Image.fs:21-26) for local PNG / PPM files; ImageLoader.cpp.
+// Whole file into `out`; false for anything that cannot be read as a regular file (missing, a directory, an I/O error).
+bool readWholeFile(const std::string& path, std::string& out);
 bool loadImageRgb24(const std::string& path, int& width, int& height, std::vector<uint8_t>& rgb, std::string& error);
 // Parsers.pcolour (SceneParser.fs:85-87), exposed for the reference's own colour tests.
 bool parseColour(const std::string& text, Colour& out);

@@ -1,6 +1,7 @@
 // SceneParser.cpp — the `.scene` DSL of SceneParser.fs:11-366 and the ASCII PLY layout of
 // PlyParser.fs:20-69 as a hand-written recursive-descent parser (the reference uses FParsec).
 // Same grammar, same section order (options, objects, lights), same units (angles in degrees).
+#include <cstdio>
 #include <cctype>
 #include <cmath>
 #include <cstdlib>
@@ -150,12 +151,11 @@ struct Parser {
     }
     std::shared_ptr<const std::vector<Triangle>> loadPly(const std::string& f) {
         std::string path = resolvePath(f);
-        std::ifstream in(path, std::ios::binary);
-        if (!in) throw ParseError{"cannot open mesh file: " + path};
-        std::stringstream ss; ss << in.rdbuf();
+        std::string text;
+        if (!readWholeFile(path, text)) throw ParseError{"cannot open mesh file: " + path};
         auto tris = std::make_shared<std::vector<Triangle>>();
         std::string err;
-        if (!parsePly(ss.str(), *tris, err)) throw ParseError{err};                              // SceneParser.fs:123-124, 135-136 raise
+        if (!parsePly(text, *tris, err)) throw ParseError{err};                              // SceneParser.fs:123-124, 135-136 raise
         return tris;
     }
 
@@ -356,10 +356,23 @@ struct Parser {
 
 } // namespace
 
+bool readWholeFile(const std::string& path, std::string& out) {
+    out.clear();
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    const bool ok = !std::ferror(f);                                // a directory opens but cannot be read (EISDIR)
+    std::fclose(f);
+    return ok;
+}
+
 bool parseScene(const std::string& text, const std::string& baseDir, SceneOptions& options, Scene& scene, std::string& error) {
     Parser p(text, baseDir);
     try { p.run(options, scene); }
     catch (const ParseError& e) { error = e.msg; return false; }
+    catch (const std::exception& e) { error = std::string("scene parser: ") + e.what(); return false; }   // nothing may cross the C boundary
     return true;
 }
 

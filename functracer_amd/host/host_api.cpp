@@ -143,13 +143,12 @@ fth_scene* fth_parse_scene(const char* text, const char* base_dir, char* err, in
 }
 fth_scene* fth_parse_scene_file(const char* path, char* err, int32_t err_len) {
     if (!path) { put_err(err, err_len, "null path"); return nullptr; }
-    std::ifstream in(path, std::ios::binary);
-    if (!in) { put_err(err, err_len, std::string("cannot open ") + path); return nullptr; }
-    std::stringstream ss; ss << in.rdbuf();
+    std::string text;
+    if (!readWholeFile(path, text)) { put_err(err, err_len, std::string("cannot open ") + path); return nullptr; }
     std::string p(path);
     size_t slash = p.find_last_of('/');
     std::string dir = slash == std::string::npos ? "." : p.substr(0, slash);
-    return fth_parse_scene(ss.str().c_str(), dir.c_str(), err, err_len);
+    return fth_parse_scene(text.c_str(), dir.c_str(), err, err_len);
 }
 void fth_scene_free(fth_scene* s) { delete s; }
 
@@ -199,7 +198,9 @@ int32_t fth_parse_colour(const char* text, double rgb[3]) {
 
 int64_t fth_parse_ply(const char* text, double* out, int64_t cap, char* err, int32_t err_len) {
     std::vector<Triangle> tris; std::string e;
-    if (!text || !parsePly(text, tris, e)) { put_err(err, err_len, e); return -1; }
+    bool ok = false;
+    try { ok = text && parsePly(text, tris, e); } catch (const std::exception& x) { e = std::string("ply parser: ") + x.what(); }   // nothing may cross the C boundary
+    if (!ok) { put_err(err, err_len, e); return -1; }
     if (out) for (int64_t i = 0; i < (int64_t)tris.size() && i < cap; ++i) {
         const Triangle& t = tris[(size_t)i];
         const double v[9] = {t.a[0], t.a[1], t.a[2], t.b[0], t.b[1], t.b[2], t.c[0], t.c[1], t.c[2]};
@@ -210,7 +211,9 @@ int64_t fth_parse_ply(const char* text, double* out, int64_t cap, char* err, int
 
 int64_t fth_load_image(const char* path, int32_t* width, int32_t* height, uint8_t* out, int64_t cap, char* err, int32_t err_len) {
     std::vector<uint8_t> rgb; std::string e; int w = 0, h = 0;
-    if (!path || !loadImageRgb24(path, w, h, rgb, e)) { put_err(err, err_len, e); return FT_ERR_INVALID; }
+    bool ok = false;
+    try { ok = path && loadImageRgb24(path, w, h, rgb, e); } catch (const std::exception& x) { e = std::string("image loader: ") + x.what(); }
+    if (!ok) { put_err(err, err_len, e); return FT_ERR_INVALID; }
     if (width) *width = w;
     if (height) *height = h;
     if (out && cap >= (int64_t)rgb.size()) std::memcpy(out, rgb.data(), rgb.size());

@@ -144,6 +144,10 @@ def test_unsupported_surface_is_rejected_loudly():
     with pytest.raises(ValueError) as e:                      # like the reference, a texture that cannot be loaded fails the parse
         ft.parse_scene('(texture image "no-such-file.png" sphere)\n')
     assert "cannot open image file" in str(e.value)
+    for src, what in (('bspMesh 0 "meshes"\n', "cannot open mesh file"), ('(texture image "textures" sphere)\n', "cannot open image file")):
+        with pytest.raises(ValueError) as e:                  # a directory where a file is expected is a parse error too (found by tools/fuzz_parsers.py)
+            ft.parse_scene(src, base_dir=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes"))
+        assert what in str(e.value)
     with pytest.raises(ValueError) as e:                      # Textures/Image.fs:11-13 fetches URLs; there is no network here
         ft.parse_scene('(texture image "http://example.invalid/moon.jpg" sphere)\n')
     assert "URL" in str(e.value)
