@@ -13,7 +13,7 @@ for name, spp in [("bunny", 16), ("hollow-sphere", 16), ("hollow-sphere", 1), ("
     p.lower(ctx)
     jit = ft.jitter_pattern(spp)
     row = []
-    for mi in (4, 6, 8, 12, 16, 24):
+    for mi in (8, 16, 24, 32, 64):
         ctx.set_option("chunk_samples", mi << 20)
         best = 1e9
         for _ in range(4):
