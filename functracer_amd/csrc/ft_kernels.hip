@@ -569,7 +569,11 @@ template <bool ANY>
 FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit) {
     bool alive = q.active && !(ANY && q.blocked);
     if (!__any(alive)) return;
-    const double ivx = 1.0 / r.dx, ivy = 1.0 / r.dy, ivz = 1.0 / r.dz;
+    // 1/d, kept finite: a direction component of (nearly) zero stands for 1e150 of its sign, which orders the two planes of a slab
+    // exactly like the infinite value would against every finite distance, without the inf - inf of the fused form below.
+    const double ivx = fabs(r.dx) < 1e-150 ? copysign(1e150, r.dx) : 1.0 / r.dx, ivy = fabs(r.dy) < 1e-150 ? copysign(1e150, r.dy) : 1.0 / r.dy,
+                 ivz = fabs(r.dz) < 1e-150 ? copysign(1e150, r.dz) : 1.0 / r.dz;
+    const double oix = r.ox * ivx, oiy = r.oy * ivy, oiz = r.oz * ivz;
     double bound = ANY ? q.max_dist : q.best_t;
     uint32_t best_tri = 0xFFFFFFFFu;
     bool found = false;
@@ -590,11 +594,13 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 cdp bx = nd + 6 * c;
-                double t0 = (bx[0] - r.ox) * ivx, t1 = (bx[3] - r.ox) * ivx;
+                // (b - o) / d as one fused multiply-add per plane, b * (1/d) - o * (1/d).  Its rounding error is of the order of
+                // 1e-16 |o| in space, far inside the 1e-7 x extent by which the builder inflates every box.
+                double t0 = __builtin_fma(bx[0], ivx, -oix), t1 = __builtin_fma(bx[3], ivx, -oix);
                 double tmin = fmin(t0, t1), tmax = fmax(t0, t1);
-                t0 = (bx[1] - r.oy) * ivy; t1 = (bx[4] - r.oy) * ivy;
+                t0 = __builtin_fma(bx[1], ivy, -oiy); t1 = __builtin_fma(bx[4], ivy, -oiy);
                 tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
-                t0 = (bx[2] - r.oz) * ivz; t1 = (bx[5] - r.oz) * ivz;
+                t0 = __builtin_fma(bx[2], ivz, -oiz); t1 = __builtin_fma(bx[5], ivz, -oiz);
                 tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
                 const bool enter = alive && tmax >= fmax(tmin, 0.0) && tmin <= bound;
                 m[c] = ch[c] == INT32_MIN ? 0ull : __ballot(enter);
