@@ -20,3 +20,12 @@ bands = tiling.bands_for_rank(3840, 2160, 0, 8)
 for _ in range(2):
     _, st = ctx.render(p.camera, 3840, 2160, 64, jit, tiles=bands, fetch=False)
 print("rank 0 of 8:", round(st["kernel_ms"], 2), "ms", round(st["rays_traced"] / st["kernel_ms"] / 1e3), "Mrays/s", st["n_chunks"], "chunks")
+# the bench's weak-scaling frames: 1920x1080 at 16 x N spp, the share of rank 0 of N (per-rank work as at N = 1)
+for n in (1, 2, 4, 8):
+    jit = ft.jitter_pattern(16 * n)
+    bands = tiling.bands_for_rank(1920, 1080, 0, n) if n > 1 else None
+    best = None
+    for _ in range(4):
+        _, st = ctx.render(p.camera, 1920, 1080, 16 * n, jit, tiles=bands, fetch=False)
+        if best is None or st["kernel_ms"] < best["kernel_ms"]: best = st
+    print(f"bench share, rank 0 of {n}: {best['kernel_ms']:.3f} ms, {best['rays_traced'] / best['kernel_ms'] / 1e3:.0f} Mrays/s, {best['n_chunks']} chunk(s), wall {best['wall_ms']:.3f} ms")
