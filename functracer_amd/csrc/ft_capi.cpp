@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -452,14 +453,8 @@ static int32_t retire_pending(ft_context* c, ft_stats* stats);
 static int32_t render_frame(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats);
 
-// The reference's hit lists are unbounded F# lists; the device's are sized at commit time.  A line that crosses a mesh under CSG
-// more often than "csg_mesh_capacity" allows is detected (never truncated): the blocking call then doubles the capacity,
-// re-commits the scene and renders the frame again, so the caller sees the reference's result without tuning anything.  The
-// larger capacity stays for the following frames.  Only when the lists stop fitting is FT_ERR_OVERFLOW handed to the caller.
-int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                  int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
-    if (!c) return FT_ERR_INVALID;
-    int32_t rc = render_frame(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats);
+static int32_t with_growing_hit_lists(ft_context* c, const std::function<int32_t()>& run) {
+    int32_t rc = run();
     while (rc == FT_ERR_OVERFLOW && c->csg_auto_grow && c->graph.csg_mesh_capacity < 255) {
         const int32_t before = c->graph.csg_mesh_capacity;
         const std::string why = c->err;
@@ -469,9 +464,19 @@ int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t re
             if (ft_scene_commit(c) == FT_OK) c->err = why;
             return FT_ERR_OVERFLOW;
         }
-        rc = render_frame(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats);
+        rc = run();
     }
     return rc;
+}
+
+// The reference's hit lists are unbounded F# lists; the device's are sized at commit time.  A line that crosses a mesh under CSG
+// more often than "csg_mesh_capacity" allows is detected (never truncated): the blocking call then doubles the capacity,
+// re-commits the scene and renders the frame again, so the caller sees the reference's result without tuning anything.  The
+// larger capacity stays for the following frames.  Only when the lists stop fitting is FT_ERR_OVERFLOW handed to the caller.
+int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                  int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
+    if (!c) return FT_ERR_INVALID;
+    return with_growing_hit_lists(c, [&] { return render_frame(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats); });
 }
 
 static int32_t render_frame(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
@@ -809,7 +814,12 @@ int32_t ft_get_kernel_times(ft_context* c, double ms[4], int32_t launches[4]) {
 }
 
 // ------------------------------------------------------------------------------------------ debug / tests
+static int32_t debug_closest(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t* hit, double* t, double* p, double* nrm, double* colour);
 int32_t ft_debug_closest(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t* hit, double* t, double* p, double* nrm, double* colour) {
+    if (!c) return FT_ERR_INVALID;
+    return with_growing_hit_lists(c, [&] { return debug_closest(c, origins, dirs, n, hit, t, p, nrm, colour); });
+}
+static int32_t debug_closest(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t* hit, double* t, double* p, double* nrm, double* colour) {
     if (!c || !origins || !dirs || n < 0 || !hit || !t || !p || !nrm || !colour) return FT_ERR_INVALID;
     if (!need_device(c)) return FT_ERR_NO_DEVICE;
     if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }
@@ -842,7 +852,12 @@ int32_t ft_debug_closest(ft_context* c, const double* origins, const double* dir
     return FT_OK;
 }
 
+static int32_t debug_blocked(ft_context* c, const double* origins, const double* dirs, const double* max_dist, int64_t n, int32_t* blocked);
 int32_t ft_debug_blocked(ft_context* c, const double* origins, const double* dirs, const double* max_dist, int64_t n, int32_t* blocked) {
+    if (!c) return FT_ERR_INVALID;
+    return with_growing_hit_lists(c, [&] { return debug_blocked(c, origins, dirs, max_dist, n, blocked); });
+}
+static int32_t debug_blocked(ft_context* c, const double* origins, const double* dirs, const double* max_dist, int64_t n, int32_t* blocked) {
     if (!c || !origins || !dirs || !max_dist || n < 0 || !blocked) return FT_ERR_INVALID;
     if (!need_device(c)) return FT_ERR_NO_DEVICE;
     if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }

@@ -136,7 +136,7 @@ int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out
 void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);
 /* Tunables: "chunk_samples" (samples in flight per launch; default 16 Mi, frames whose pixel blocks are classified use twice that), "csg_mesh_capacity" (hit-list entries a mesh may add under
- * CSG; default 32), "csg_auto_grow" (default 1: a blocking ft_render whose hit lists overflow doubles that capacity, re-commits and renders the
+ * CSG; default 32), "csg_auto_grow" (default 1: a blocking ft_render (and the ft_debug_* ray queries) whose hit lists overflow doubles that capacity, re-commits and renders the
  * frame again instead of returning FT_ERR_OVERFLOW; the error remains for lists that stop fitting in the LDS and for ft_render_enqueue), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around every
  * k_closest / k_shade launch, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
  * cannot reach any object are finished before any ray is generated), "tail_rays" (a bounce starting with fewer rays is finished by the tail
