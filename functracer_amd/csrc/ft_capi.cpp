@@ -454,6 +454,14 @@ static int32_t render_frame(ft_context* c, const ft_camera* cam, int32_t res_h, 
                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats);
 
 static int32_t with_growing_hit_lists(ft_context* c, const std::function<int32_t()>& run) {
+    // Frames still queued by ft_render_enqueue are retired first, so that an overflow of one of THEM is reported as what it is
+    // (queued frames are not rendered again) instead of being taken for this call's.
+    if (!c->host_only && (c->slots[0].pending || c->slots[1].pending)) {
+        if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return FT_ERR_NO_DEVICE; }
+        const int32_t prc = retire_pending(c, nullptr);
+        c->accum_open = false;
+        if (prc != FT_OK) return prc;
+    }
     int32_t rc = run();
     while (rc == FT_ERR_OVERFLOW && c->csg_auto_grow && c->graph.csg_mesh_capacity < 255) {
         const int32_t before = c->graph.csg_mesh_capacity;

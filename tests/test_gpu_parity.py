@@ -620,6 +620,14 @@ def test_overflowing_hit_lists_grow_and_the_frame_still_matches(hip):
         assert hip.scene_info()["csg_capacity"] > small           # and the larger lists stay for the next frame
         again, _ = hip.render(cam, 96, 64, 1, jit)
         assert np.array_equal(again, got)
+        hip.set_option("csg_mesh_capacity", 2)                    # a QUEUED frame is not rendered again: its overflow is reported, by
+        build(hip)                                                # whichever call retires it, and not mistaken for that call's own
+        hip.render_enqueue(cam, 96, 64, 1, jit)
+        with pytest.raises(FtError, match="OVERFLOW"):
+            hip.render(cam, 96, 64, 1, jit)
+        assert hip.scene_info()["csg_capacity"] == small
+        once_more, _ = hip.render(cam, 96, 64, 1, jit)            # nothing queued now: this one grows and delivers
+        assert np.array_equal(once_more, got)
     finally:
         hip.set_option("csg_auto_grow", 1)
         hip.set_option("csg_mesh_capacity", 32)
