@@ -162,7 +162,7 @@ def test_config_scene_frames_match_oracle(hip, name, w, h, spp):
 
 
 def test_golden_frames(hip):
-    """Committed oracle frames (tests/golden/frames.npz, made by tools/make_goldens.py)."""
+    """Committed oracle frames (tests/golden/frames.npz, made by tests/tools/make_goldens.py)."""
     import os
     path = os.path.join(H.ROOT, "tests", "golden", "frames.npz")
     z = np.load(path)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size pixel parity of the HIP path against the CPU oracle on the BASELINE configurations
-(the oracle uses every host core).  Writes a JSON summary: python tools/full_parity.py > profiles/parity_full.json"""
+(the oracle uses every host core).  Writes a JSON summary: python tests/tools/full_parity.py > profiles/parity_full.json"""
 import json
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import functracer_amd as ft  # noqa: E402
 from oracle import ft_oracle_py as O  # noqa: E402

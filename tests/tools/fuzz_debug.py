@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Diagnose a failing random scene of tests/test_gpu_fuzz.py: python tools/fuzz_debug.py <seed> ...  (GPU box)"""
+"""Diagnose a failing random scene of tests/test_gpu_fuzz.py: python tests/tools/fuzz_debug.py <seed> ...  (GPU box)"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import functracer_amd as ft  # noqa: E402
 from oracle import ft_oracle_py as O  # noqa: E402

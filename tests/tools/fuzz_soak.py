@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """One-off soak of the random-scene parity checks over many more seeds than the test suite carries:
-   python tools/fuzz_soak.py <first> <count>      (GPU box; prints the seeds that fail)"""
+   python tests/tools/fuzz_soak.py <first> <count>      (GPU box; prints the seeds that fail)"""
 import os
 import sys
 import traceback
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import functracer_amd as ft  # noqa: E402
 from tests import test_gpu_fuzz as F  # noqa: E402
