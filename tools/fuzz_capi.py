@@ -37,7 +37,8 @@ while time.time() < t_end:
     nodes = []
 
     def pick():
-        if not nodes or rng.random() < 0.05: return rng.choice([-1, 10 ** 6, -2 ** 31, 2 ** 31 - 1])   # not a node
+        if not nodes: nodes.append(ctx.primitive(ft.SPHERE))
+        if rng.random() < 0.03: return rng.choice([-1, 10 ** 6, -2 ** 31, 2 ** 31 - 1])   # not a node
         return rng.choice(nodes)
 
     try:
