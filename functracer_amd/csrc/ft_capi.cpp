@@ -605,7 +605,14 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     const bool classifiable = c->classify_pixels && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && !c->flat.unbounded;
     const int64_t chunk_budget = classifiable ? 2 * c->chunk_samples : c->chunk_samples;
     int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, chunk_budget / spp));
-    if (pix_per_chunk > 64) pix_per_chunk -= pix_per_chunk % 64;      // keep 8x8 blocks (= wavefronts) whole
+    if (pix_per_chunk > 64) {
+        // equal chunks rather than full ones and a remainder: a short last chunk is all latency (measured on night-house at
+        // 1080p x 16: 25 M + 8 M samples 5.35 ms, 2 x 16.6 M 4.83 ms); 8x8 blocks (= wavefronts) stay whole
+        const int64_t n_chunks = (n_pix_total + pix_per_chunk - 1) / pix_per_chunk;
+        const int64_t even = ((n_pix_total + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+        pix_per_chunk -= pix_per_chunk % 64;
+        if (even < pix_per_chunk) pix_per_chunk = even;
+    }
     int64_t cap = pix_per_chunk * spp;
     if (corner) { cap = 1; for (auto& j : jobs) cap = std::max<int64_t>(cap, j.n_ids); }
     else for (int64_t p0 = 0; p0 < n_pix_total; p0 += pix_per_chunk) {
