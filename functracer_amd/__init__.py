@@ -237,10 +237,10 @@ class Context(SceneBuilder):
         return st.as_dict()
 
     def kernel_times(self):
-        ms = np.zeros(4)
-        n = np.zeros(4, dtype=np.int32)
+        ms = np.zeros(5)
+        n = np.zeros(5, dtype=np.int32)
         self._check(self._lib.ft_get_kernel_times(self._ctx, _capi.dptr(ms), n.ctypes.data_as(_capi.c_int32_p)))
-        names = ["other", "closest", "shade", "blend"]   # "other": memsets, k_classify, statistics (and k_blend unless "timing" = 2)
+        names = ["other", "closest", "shade", "blend", "primary"]   # "other": memsets, k_classify, statistics (and k_blend unless "timing" = 2)
         return {k: {"ms": float(ms[i]), "launches": int(n[i])} for i, k in enumerate(names)}
 
     def closest(self, origins, dirs):
@@ -269,6 +269,16 @@ class Context(SceneBuilder):
         keys = ["leaves", "program_words", "meshes", "bsp_nodes", "bsp_leaves", "triangles", "csg_capacity", "stack_capacity", "items", "bounded_items",
                 "unbounded", "face_directions"]
         return dict(zip(keys, list(out)))
+
+
+def rays_handled_by(kernel, st):
+    """Rays one frame's launches of `kernel` trace, from the frame's ft_stats (bench.py's roofline line)."""
+    generated = st["rays_primary"] - st["rays_primary_culled"]
+    if kernel == "primary":                                         # fused bounce 0: every generated primary ray + the shadow rays of its hits
+        return generated + st["rays_shadow_primary"] if "rays_shadow_primary" in st else generated + st["rays_shadow"]
+    if kernel == "closest":
+        return st["rays_reflect"] - min(st["rays_reflect"], st["rays_tail"])
+    return st["rays_shadow"]
 
 
 def debug_slice(p0, n, tri):

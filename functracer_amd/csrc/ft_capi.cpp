@@ -17,6 +17,7 @@
 #include "ft_scene.h"
 
 namespace ftk {
+int occupancy_blocks_primary(size_t lds_bytes, int variant);
 int occupancy_blocks_closest(size_t lds_bytes, int variant);
 int occupancy_blocks_shade(size_t lds_bytes, int variant);
 }
@@ -31,6 +32,7 @@ struct ft_context {
     bool host_only = false;
     int device = -1;
     int n_cu = 0;
+    uint32_t n_stat_slots = 0;      // one RenderCounters slot per wave of the largest persistent grid: n_cu x 8 blocks x 4 waves
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -42,6 +44,7 @@ struct ft_context {
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
     int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
+    bool fused_primary = true;      // bounce 0 through k_primary (one kernel) instead of k_closest + k_shade
     int64_t tail_rays = 262144;      // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM
@@ -73,8 +76,8 @@ struct ft_context {
     DeviceBuf d_out_index;
     int64_t last_n_pix = 0;
     int32_t last_res_h = 0, last_res_v = 0;
-    double k_ms[4] = {0, 0, 0, 0};
-    int32_t k_launches[4] = {0, 0, 0, 0};
+    double k_ms[5] = {0, 0, 0, 0, 0};
+    int32_t k_launches[5] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -187,6 +190,7 @@ static int32_t create_single(int32_t device_id, int count, ft_context** out) {
     if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FT_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
+    c->n_stat_slots = (uint32_t)c->n_cu * 8u * (uint32_t)(ftk::kBlock / 64);   // every grid is n_cu x (at most 8) blocks (clamp_blocks, Lg)
     *out = c;
     return FT_OK;
 }
@@ -246,6 +250,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "coherent_waves")) { c->coherent_waves = value != 0; c->dev_scene.coherent_waves = value != 0 ? 1 : 0; for (ft_context* p : c->peers) { p->coherent_waves = value != 0; p->dev_scene.coherent_waves = c->dev_scene.coherent_waves; } return FT_OK; }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
+    if (!std::strcmp(key, "fused_primary")) { c->fused_primary = value != 0; for (ft_context* p : c->peers) p->fused_primary = value != 0; return FT_OK; }
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
     if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
@@ -389,7 +394,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_coarse, f.coarse_boxes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 2))) != FT_OK) return rc;   // + one slot's worth for the frame's PixCount
+    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters) * ((size_t)c->n_stat_slots + 2))) != FT_OK) return rc;   // + one slot's worth for the frame's PixCount
     FT_HIP(c, hipStreamSynchronize(c->stream));
     ftk::DevScene& S = c->dev_scene;
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
@@ -602,7 +607,13 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     // k_shade slower than the blocks save).  A classified frame's chunks are windows of its ACTIVE pixel list, usually a fraction
     // of the frame: they are twice as wide (measured at 1080p x 16: bunny 0.58 -> 0.55 ms, hollow-sphere 6.1 -> 5.8, sample 1.64 ->
     // 1.50; the unclassified night-house loses 14 % at that width and keeps the narrow one).
-    const bool classifiable = c->classify_pixels && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && !c->flat.unbounded;
+    // k_classify bounds every sample of a pixel by a square of +-extent pixels around its centre.  The reference's offsets lie in the
+    // unit disc (Jitter.fs:15-21) but the pattern is the caller's: the square follows the pattern, and a pattern with a non-finite
+    // or absurd offset turns classification off instead of bounding nothing.
+    double jitter_extent = 1.0;
+    bool jitter_bounded = true;
+    if (!corner) for (size_t k = 0; k < 2 * (size_t)spp; ++k) { const double v = jitter_xy[k]; if (!(std::fabs(v) <= 64.0)) jitter_bounded = false; else jitter_extent = std::max(jitter_extent, std::fabs(v)); }
+    const bool classifiable = c->classify_pixels && jitter_bounded && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && !c->flat.unbounded;
     const int64_t chunk_budget = classifiable ? 2 * c->chunk_samples : c->chunk_samples;
     int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, chunk_budget / spp));
     if (pix_per_chunk > 64) {
@@ -633,7 +644,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         c->jitter_on_device = jit;                                 // (the copy source outlives this call)
         if ((rc = upload(c, c->d_jitter, c->jitter_on_device)) != FT_OK) return rc;
     }
-    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * (ftk::kStatSlots + 2), c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * ((size_t)c->n_stat_slots + 2), c->stream));
 
     bool classify = classifiable && pix_per_chunk % 64 == 0;
     for (const Job& j : jobs) if (j.n_ids % 64u) classify = false;
@@ -653,6 +664,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds, variant), lds, variant};
     ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds, variant), lds, variant};
     ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_tail(lds, variant), lds, variant};
+    ftk::Launch Lp{c->stream, c->n_cu * ftk::occupancy_blocks_primary(lds, variant), lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
     const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
@@ -662,10 +674,10 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     auto* rcount = c->d_rc.as<ftk::RenderCounters>();
 
     // A blocking call retires whatever is in flight first; a deferred one only the frame whose slot it is about to reuse.
-    if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
+    if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < 5; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
     ft_context::FrameSlot& F = c->slots[c->slot_turn];
     if (F.pending) { int32_t prc = retire_frame(c, F, nullptr); if (prc != FT_OK) return prc; }
-    if (defer && !c->accum_open) { for (int k = 0; k < 4; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = true; }
+    if (defer && !c->accum_open) { for (int k = 0; k < 5; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = true; }
     F.events_used = 0; F.spans.clear();
     auto& spans = F.spans;
     using Span = ft_context::FrameSlot::Span;
@@ -678,7 +690,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     bool boundary_fresh = true;                                    // `boundary` was recorded right before the next launch
     const int timing = c->timing;
     auto timed = [&](int kind, auto&& fn) {
-        const bool bracket = timing >= 2 || (timing == 1 && (kind == 1 || kind == 2));
+        const bool bracket = timing >= 2 || (timing == 1 && (kind == 1 || kind == 2 || kind == 4));
         if (bracket && !boundary_fresh) { boundary = next_event(F); if (boundary) (void)hipEventRecord(boundary, c->stream); }
         fn();
         if (!bracket) { boundary_fresh = false; return; }
@@ -690,13 +702,13 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     int n_chunks = 0, n_launches = 0;
     // The whole frame is classified once; the chunks then take consecutive windows of the frame's ACTIVE pixel list, so a sparse
     // frame is one chunk of real work and launches that find their window empty return at once.
-    ftk::PixCount* const frame_counts = reinterpret_cast<ftk::PixCount*>(rcount + ftk::kStatSlots + 1);
+    ftk::PixCount* const frame_counts = reinterpret_cast<ftk::PixCount*>(rcount + c->n_stat_slots + 1);
     if (classify) {
         const ftk::Primary all{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), 0u, (uint32_t)n_pix_total, spp, (uint32_t)res_h,
                                (unsigned long long)seed, 1.0 / (double)n_pix_total, 1.0 / (double)res_h, nullptr};
         const size_t n_seg = ((size_t)n_pix_total / 64 + ftk::kClassifySegmentBlocks - 1) / ftk::kClassifySegmentBlocks;
         timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, all, c->d_block_flags.as<uint8_t>() + n_seg * 4, c->d_block_flags.as<uint32_t>(), c->d_active_ids.as<uint32_t>(),
-                                            c->d_active_pos.as<uint32_t>(), frame_counts, c->d_out.as<double>(), whole ? 1 : 0, rcount); });
+                                            c->d_active_pos.as<uint32_t>(), frame_counts, c->d_out.as<double>(), whole ? 1 : 0, jitter_extent, rcount); });
         n_launches += 2;
     }
     for (const Job& job : jobs) {
@@ -710,6 +722,11 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         double* const chunk_out = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
         if (classify) { gen.pixel_ids = c->d_active_ids.as<uint32_t>(); gen.counts = frame_counts; }   // pix_base = job.id_base: the window's start
         for (int b = 0; b <= last_bounce; ++b) {
+            if (b == 0 && c->fused_primary) {
+                timed(4, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, max_depth, cc, rcount); });
+                ++n_launches;
+                continue;
+            }
             timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, (uint32_t)c->tail_rays, cc, rcount); });
             timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
             n_launches += 2;
@@ -725,7 +742,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, classify ? frame_counts : nullptr, job.id_base, spp, out_index, out_ptr); });
         ++n_launches;
     }
-    timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, ftk::kStatSlots); });
+    timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, c->n_stat_slots); });
     if (boundary_fresh) ev1 = boundary;
     else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
     FT_HIP(c, hipGetLastError());
@@ -754,7 +771,7 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
     const int timing = F.timing; const int32_t spp = F.spp; const int64_t n_pix_total = F.n_pix_total; const bool classify = F.classify;
     hipEvent_t ev0 = F.ev0, ev1 = F.ev1;
     double k1 = 0.0, k2 = 0.0;
-    for (auto& s : F.spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; if (s.kind == 1) k1 += ms; if (s.kind == 2) k2 += ms; } }
+    for (auto& s : F.spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; if (s.kind == 1) k1 += ms; if (s.kind == 2 || s.kind == 4) k2 += ms; } }
     if (timing < 2) {                                              // index 0 = everything that was not bracketed (memsets, k_classify, k_blend, statistics)
         float total = 0; if (ev0 && ev1) (void)hipEventElapsedTime(&total, ev0, ev1);
         c->k_ms[0] += std::max(0.0, (double)total - k1 - k2);
@@ -765,7 +782,10 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
         if (ev0 && ev1) (void)hipEventElapsedTime(&ms, ev0, ev1);
         stats->rays_primary = F.rays_primary;
         stats->rays_shadow = hrc.rays_shadow; stats->rays_reflect = hrc.rays_reflect;
-        stats->rays_traced = stats->rays_primary + stats->rays_shadow + stats->rays_reflect;
+        // rays the device really traced: primaries of pixel blocks k_classify finished (Colour.Zero for the whole block, no ray generated)
+        // are part of rays_primary and of the reference-equivalent count, not of rays_traced
+        stats->rays_primary_culled = (uint64_t)hrc.pixels_culled * (uint64_t)spp;
+        stats->rays_traced = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, stats->rays_primary_culled) + stats->rays_shadow + stats->rays_reflect;
         stats->rays_reference_equivalent = (double)stats->rays_primary + hrc.ref_equiv;
         stats->hits_primary = hrc.hits_primary; stats->csg_overflow = hrc.csg_overflow;
         stats->kernel_ms = ms; stats->trace_kernel_ms = k1 + k2;
@@ -776,7 +796,6 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
             const uint64_t H = HH - std::min(HH, Th), H0 = hrc.hits_primary, HL = H - std::min(H, H0);
             stats->hits_total = hrc.hits_total;
             stats->rays_tail = Ti + Tr;
-            stats->rays_primary_culled = Pc;
             stats->algorithmic_bytes_closest = P * (ftk::kPixelIdBytes + ftk::kTouchedBytes) + R * 48 + H * (ftk::kHitRecBytes + ftk::kListBytes);
             stats->algorithmic_bytes_shade = H * (ftk::kHitRecBytes + ftk::kListBytes) + H0 * (2 * ftk::kPixelIdBytes + ftk::kAccBytes) +
                                              HL * (48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + Rw * ftk::kRayRecBytes;
@@ -822,9 +841,9 @@ int32_t ft_render_wait(ft_context* c, ft_stats* stats) {
     return rc;
 }
 
-int32_t ft_get_kernel_times(ft_context* c, double ms[4], int32_t launches[4]) {
+int32_t ft_get_kernel_times(ft_context* c, double ms[5], int32_t launches[5]) {
     if (!c || !ms || !launches) return FT_ERR_INVALID;
-    for (int k = 0; k < 4; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
+    for (int k = 0; k < 5; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
     return FT_OK;
 }
 

@@ -108,13 +108,17 @@ void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayB
 // finished on the spot (its output pixels are written as Colour.Zero); the others are compacted into the chunk's active
 // pixel list, which is all the later stages see.
 void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint8_t* block_active, uint32_t* segment_count, uint32_t* active_ids,
-                     uint32_t* active_pos, PixCount* counts, double* out, int whole, RenderCounters* rc);
+                     uint32_t* active_pos, PixCount* counts, double* out, int whole, double jitter_extent, RenderCounters* rc);
 constexpr uint32_t kClassifySegmentBlocks = 256;               // blocks per compaction segment (ft_kernels.hip: kSegmentBlocks)
 // Tail of the bounce loop (k_tail): once a bounce has fewer than `threshold` rays the per-bounce stages stand down and this one
 // launch follows every remaining path to its end inside registers.
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
                  int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc);
 int occupancy_blocks_tail(size_t lds_bytes, int variant);
+// Bounce 0 fused (k_primary): generate, closest hit, shadow queries, shaders and reflection spawn for the frame's primary rays.
+void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint8_t* touched, uint32_t acc_stride, int max_depth,
+                    ChunkCounters* cc, RenderCounters* rc);
+int occupancy_blocks_primary(size_t lds_bytes, int variant);
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
                   double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
 // K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
@@ -122,8 +126,8 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
 void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, uint32_t first, int32_t spp, const uint32_t* out_index, double* out_rgb);
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
 void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
-// Sum the per-wave statistic slots 1..n_slots into slot 0 (one block).
-constexpr uint32_t kStatSlots = 8192;   // >= waves of the largest persistent grid (256 CUs x 8 blocks x 4 waves)
+// Sum the per-wave statistic slots 1..n_slots into slot 0.  The caller sizes the slots from the device: n_cu x 8 blocks x 4 waves,
+// the largest grid any launcher here uses (persistent grids are n_cu x clamp_blocks(occupancy) <= 8, the others are clamped to n_cu x 8).
 void launch_reduce_stats(const Launch& L, RenderCounters* slots, uint32_t n_slots);
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,

@@ -1451,9 +1451,122 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_primary: bounce 0 as ONE kernel (the north star's fused megakernel, used where the work is coherent).  A wave takes a batch of
+// 64 primary rays - one 8x8 pixel block for one jitter offset - generates them (Image.fs:83-89), finds their closest hits as a
+// packet, and for the lanes that hit goes straight on to the shadow queries and the shaders (Shading.fs:109-139) with the ray,
+// the hit and the surface still in registers: no hit record, no hit list, no second generation of the ray, and the block's shadow
+// rays stay one tight bundle instead of being compacted with those of other blocks.  Every live lane stores its sample's colour
+// (Colour.Zero for a miss: Scene.fs:116), so the accumulator planes are written in whole lines; reflection rays are spawned into
+// the bounce-1 wavefront buffer exactly as k_shade does.  Same device functions in the same order per sample as the staged
+// kernels, so a frame does not depend on which of the two routes bounce 0 takes.
+struct PrimaryArgs {
+    DevScene S; Primary gen; RayBuf next;
+    double* acc; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc;
+    uint32_t acc_stride; int32_t max_depth;
+};
+#ifndef FT_PRIMARY_BLOCKS
+#define FT_PRIMARY_BLOCKS 2
+#endif
+template <bool FANCY, bool SOFT, bool MESH>
+__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_primary(PrimaryArgs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const FT_CONST PrimaryArgs* K = kernel_args<PrimaryArgs>();
+    const Scene S = scene_view(K->S);
+    ChunkCounters* cc = K->cc;
+    const Pix px = pix_count(&K->gen);
+    const uint32_t n_pix = px.n;
+    const uint32_t n = n_pix * (uint32_t)K->gen.spp;
+    const int n_lights = S.n_lights;
+    unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
+    const uint32_t B = batch_lanes_for(n, S.lane_fold);
+    const uint32_t n_batches = (n + B - 1) / B;
+    const bool uniform_s = B == 64u && (n_pix & 63u) == 0u;
+    const bool coherent = K->S.coherent_waves != 0;
+    BatchCursor cursor(&cc->work_trace[0][0]);
+    uint32_t bi = cursor.grab(), bi_next = cursor.grab();
+    uint32_t pid_next = 0;
+    if (bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, px, bi * B + lane_id());
+    for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
+        const uint32_t i = bi * B + lane_id();
+        const uint32_t pid = pid_next;
+        const bool active = i < n && lane_id() < B;
+        // ---- closest hit (k_closest); the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
+        Ray ro{0, 0, 0, 0, 0, 0};
+        {
+            const FT_CONST PrimaryArgs* Kb = fresh(K);              // camera, pixel list: loaded here, dead before the trace
+            if (bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, px, bi_next * B + lane_id());
+            if (active) {
+                const Ray r = primary_ray_from(&Kb->gen, px, i, pid, uniform_s);
+                ro = {r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
+            }
+        }
+        Query<false> q;
+        q.active = active; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
+        bool overflow;
+        trace<false, MESH>(S, ro, q, lds, overflow, coherent);
+        n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && active));
+        const bool hit = active && q.id0 != ID_MISS;
+        const unsigned long long hit_mask = __ballot(hit);
+        double cr = 0.0, cg = 0.0, cb = 0.0;                        // a sample whose primary ray hits nothing is Colour.Zero
+        if (hit_mask) {
+            // ---- shade (k_shade)
+            Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
+            bool lit = false;
+            unsigned long long sample = 0ull;
+            if (hit) {
+                sf = surface_at<FANCY>(S, ro, q.best_t, q.id0, q.id1);
+                lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
+                if (SOFT) sample = (unsigned long long)pid * (unsigned long long)fresh(K)->gen.spp + div_by(i, px.inv);
+            }
+            unsigned long long vis_lo, vis_hi;
+            light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, 0, coherent, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
+            MaterialV mat = material_at(S, sf.material);
+            if (FANCY) { if (hit && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
+            // the view ray is generated again here rather than kept in registers across the shadow traces (same arithmetic, same value)
+            const FT_CONST PrimaryArgs* K2 = fresh(K);
+            const Ray rv = hit ? primary_ray_from(&K2->gen, px, i, pid, uniform_s) : Ray{0, 0, 0, 0, 0, 0};
+            shade_lights<FANCY, SOFT>(S, sf, mat, rv, hit, lit, vis_lo, vis_hi, cr, cg, cb);
+            // reflectionShader (Shading.fs:89-98), see k_shade: one ray of weight L * reflectance stands for the L identical sub-traces
+            const bool spawn = lit && mat.reflectance > 0.0 && 0 < K2->max_depth;
+            const unsigned long long m = __ballot(spawn);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            uint32_t dst = 0;
+            if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->cc->n_rays[1], cnt);
+            dst = __builtin_amdgcn_readfirstlane(dst);
+            if (spawn) {
+                const uint32_t o = dst + lanes_below(m);
+                const FT_CONST RayBuf& next = K2->next;
+                const double k2 = 2.0 * dot3(rv.dx, rv.dy, rv.dz, sf.n.x, sf.n.y, sf.n.z);
+                next.ox[o] = sf.p.x; next.oy[o] = sf.p.y; next.oz[o] = sf.p.z;
+                next.dx[o] = rv.dx - k2 * sf.n.x; next.dy[o] = rv.dy - k2 * sf.n.y; next.dz[o] = rv.dz - k2 * sf.n.z;
+                next.w[o] = 1.0 * (mat.reflectance * (double)n_lights);
+                next.slot[o] = i;
+            }
+            n_refl_wave += cnt;
+            n_hit_wave += (unsigned long long)__popcll(hit_mask);
+        }
+        if (active) {                                               // the sample's first contribution: a plain store (path weight 1)
+            const FT_CONST PrimaryArgs* Ka = fresh(K);
+            double* acc = Ka->acc; const uint32_t acc_stride = Ka->acc_stride;
+            acc[i] = 1.0 * cr; acc[(size_t)acc_stride + i] = 1.0 * cg; acc[2 * (size_t)acc_stride + i] = 1.0 * cb;
+            if (Ka->touched) Ka->touched[i] = 1;
+        }
+    }
+    RenderCounters* mine = my_stats(fresh(K)->rc);
+    wave_add(&mine->rays_shadow, n_shadow_wave);
+    wave_add(&mine->rays_reflect, n_refl_wave);
+    wave_add(&mine->hits_total, n_hit_wave);
+    wave_add(&mine->hits_primary, n_hit_wave);
+    wave_add(&mine->csg_overflow, n_ovf_wave);
+    if (lane_id() == 0 && (n_hit_wave || n_refl_wave))              // what the F# recursion would trace (Shading.fs:109-139), depth 0
+        mine->ref_equiv += (double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave;
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_classify: which 64-pixel blocks of the chunk can see anything at all.  One wave per block: lane = pixel; the cone around
-// the block's primary rays - ALL samples of its pixels: every jitter offset lies in the unit disc (Jitter.fs:15-21), so the
-// four rays through the corners (+-1, +-1) pixel around each pixel centre bound them - is tested against the bounding
+// the block's primary rays - ALL samples of its pixels: the reference's jitter offsets lie in the unit disc (Jitter.fs:15-21); the
+// pattern is caller-injected here, so the host passes max(1, largest |offset|) and the four rays through the corners
+// (+-extent, +-extent) pixel around each pixel centre bound them - is tested against the bounding
 // sphere of every top-level item (items_in_cone, conservative).  A block no item can be hit from is finished here: its
 // pixels are written as Colour.Zero (Scene.fs:116, no hit) and none of its W*H*spp rays is generated.  The other blocks are
 // appended to the chunk's active pixel list, in blocks of 64 so a wavefront stays one compact bundle.  The host only runs
@@ -1461,6 +1574,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
 struct ClassifyArgs {
     DevScene S; Primary gen;                                        // gen.pixel_ids / pix_base / n_pix: the chunk's full pixel list
     uint8_t* block_active; uint32_t* segment_count; double* out; RenderCounters* rc; int32_t whole;
+    double jitter_extent;                                           // max(1, largest |offset| of the caller's jitter pattern): half-width, in pixels, of the square all samples of a pixel lie in
 };
 constexpr uint32_t kSegmentBlocks = 256;                            // blocks per compaction segment (one k_compact workgroup)
 constexpr uint32_t kClassifyRun = 4;                                // consecutive blocks per wave: one list reservation for all of them
@@ -1489,7 +1603,8 @@ __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
             bool finite = true;
 #pragma unroll
             for (int c = 0; c < 5; ++c) {                           // centre, then the four corners
-                const double ox = c == 0 ? 0.0 : ((c & 1) ? 1.000001 : -1.000001), oy = c == 0 ? 0.0 : ((c & 2) ? 1.000001 : -1.000001);
+                const double ext = K->jitter_extent * 1.000001;
+                const double ox = c == 0 ? 0.0 : ((c & 1) ? ext : -ext), oy = c == 0 ? 0.0 : ((c & 2) ? ext : -ext);
                 const double jx = cxp + ox * g->cam.pw, jy = cyp + oy * g->cam.ph;
                 const double dx = (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0], dy = (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1],
                              dz = (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2];
@@ -1538,8 +1653,9 @@ __global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
                         // pixel bounds of the block (+- one pixel of jitter), as image-plane coordinates
                         const float fpx = (float)px, fpy = (float)py;
                         const float x0 = wave_min(fpx), x1 = -wave_min(-fpx), y0 = wave_min(fpy), y1 = -wave_min(-fpy);
-                        const double jx0 = g->cam.tlx + ((double)x0 - 1.001) * g->cam.pw, jx1 = g->cam.tlx + ((double)x1 + 1.001) * g->cam.pw;
-                        const double jy0 = g->cam.tly - ((double)y1 + 1.001) * g->cam.ph, jy1 = g->cam.tly - ((double)y0 - 1.001) * g->cam.ph;
+                        const double reach_px = K->jitter_extent + 0.001;
+                        const double jx0 = g->cam.tlx + ((double)x0 - reach_px) * g->cam.pw, jx1 = g->cam.tlx + ((double)x1 + reach_px) * g->cam.pw;
+                        const double jy0 = g->cam.tly - ((double)y1 + reach_px) * g->cam.ph, jy1 = g->cam.tly - ((double)y0 - reach_px) * g->cam.ph;
                         const LeafHead Hm = leaf_head(S, leaf);
                         cdp Mw = S.leaves + 16ull * leaf;
                         Ray corner[4];
@@ -1845,6 +1961,20 @@ static ShadeKernel shade_variant(int v) {                          // bit 0 FANC
     }
 }
 
+typedef void (*PrimaryKernel)(PrimaryArgs);
+static PrimaryKernel primary_variant(int v) {
+    switch (v & 7) {
+        case 0: return k_primary<false, false, false>;
+        case 1: return k_primary<true, false, false>;
+        case 2: return k_primary<false, true, false>;
+        case 3: return k_primary<true, true, false>;
+        case 4: return k_primary<false, false, true>;
+        case 5: return k_primary<true, false, true>;
+        case 6: return k_primary<false, true, true>;
+        default: return k_primary<true, true, true>;
+    }
+}
+
 typedef void (*TailKernel)(TailArgs);
 static TailKernel tail_variant(int v) {
     switch (v & 7) {
@@ -1873,9 +2003,14 @@ void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf
     const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, cc, rc, acc_stride, bounce, max_depth};
     hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
+void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint8_t* touched, uint32_t acc_stride, int max_depth,
+                    ChunkCounters* cc, RenderCounters* rc) {
+    const PrimaryArgs a{S, gen, next, acc, touched, cc, rc, acc_stride, max_depth};
+    hipLaunchKernelGGL(primary_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
+}
 void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint8_t* block_active, uint32_t* segment_count, uint32_t* active_ids,
-                     uint32_t* active_pos, PixCount* counts, double* out, int whole, RenderCounters* rc) {
-    const ClassifyArgs a{S, gen_list, block_active, segment_count, out, rc, whole};
+                     uint32_t* active_pos, PixCount* counts, double* out, int whole, double jitter_extent, RenderCounters* rc) {
+    const ClassifyArgs a{S, gen_list, block_active, segment_count, out, rc, whole, jitter_extent};
     const uint32_t n_blocks = gen_list.n_pix / 64u, n_runs = (n_blocks + kClassifyRun - 1) / kClassifyRun, n_segments = (n_blocks + kSegmentBlocks - 1) / kSegmentBlocks;
     hipLaunchKernelGGL(k_classify, dim3(blocks_for(n_runs * 64u, L.grid)), dim3(kBlock), 0, L.stream, a);
     const CompactArgs cmp{gen_list.pixel_ids + gen_list.pix_base, block_active, segment_count, active_ids, active_pos, counts, n_blocks, n_segments};
@@ -1919,6 +2054,11 @@ int occupancy_blocks_closest(size_t lds_bytes, int variant) {
 int occupancy_blocks_tail(size_t lds_bytes, int variant) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_variant(variant), kBlock, lds_bytes) != hipSuccess) n = 1;
+    return clamp_blocks(n);
+}
+int occupancy_blocks_primary(size_t lds_bytes, int variant) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, primary_variant(variant), kBlock, lds_bytes) != hipSuccess) n = 1;
     return clamp_blocks(n);
 }
 int occupancy_blocks_shade(size_t lds_bytes, int variant) {

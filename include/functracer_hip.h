@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 1
+#define FT_ABI_VERSION 2
 
 typedef struct ft_context ft_context;
 typedef int32_t ft_node;
@@ -108,7 +108,7 @@ typedef struct ft_stats {
     uint64_t rays_primary;   /* W*H*spp over the rendered tiles                                */
     uint64_t rays_shadow;    /* shadow rays actually traced                                    */
     uint64_t rays_reflect;   /* reflection rays actually traced                                */
-    uint64_t rays_traced;    /* sum of the three                                               */
+    uint64_t rays_traced;    /* rays the device traced: rays_primary - rays_primary_culled + rays_shadow + rays_reflect */
     double   rays_reference_equivalent; /* what the F# recursion would trace (Shading.fs:109-139):
                                 L shadow rays per hit and L reflection rays per reflective hit  */
     uint64_t hits_primary;   /* primary rays that hit something                                */
@@ -125,6 +125,7 @@ typedef struct ft_stats {
     uint64_t rays_tail;      /* reflection rays followed by the tail kernel (handed over + spawned inside it) */
     uint64_t rays_primary_culled; /* primary rays (part of rays_primary) resolved as misses per 64-pixel block: the block's ray
                                    * bundle cannot reach any object, so they were never generated one by one          */
+    uint64_t algorithmic_bytes_primary; /* the k_primary (fused bounce 0) share of algorithmic_bytes                          */
 } ft_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -220,9 +221,10 @@ int32_t ft_create_host_only(ft_context** out);
 int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[12]);
 int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9],
                        double above[18], int32_t* n_above, double below[18], int32_t* n_below);
-/* HIP-event time per stage over the last ft_render: index 1 closest, 2 shade (and the tail kernel); with "timing" = 2 also
- * 3 blend and 0 the rest (memsets, classification, statistics); otherwise 0 = everything but closest and shade, 3 = 0. */
-int32_t ft_get_kernel_times(ft_context* ctx, double ms[4], int32_t launches[4]);
+/* HIP-event time per stage over the last ft_render: index 4 primary (bounce 0 fused: generate + closest + shade), 1 closest and
+ * 2 shade of the later bounces (2 also holds the tail kernel); with "timing" = 2 also 3 blend and 0 the rest (memsets,
+ * classification, statistics); otherwise 0 = everything that is not bracketed, 3 = 0. */
+int32_t ft_get_kernel_times(ft_context* ctx, double ms[5], int32_t launches[5]);
 
 /* Image.write's toByte (Image.fs:36): clamp to [0,1], *255, truncate; alpha = 255. */
 int32_t ft_quantise_rgba8(const double* rgb, int64_t n_pixels, uint8_t* out_rgba);
