@@ -39,9 +39,18 @@ def hip_lib():
         lib.ft_render.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32,
                                   C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32, _capi.c_double_p, C.POINTER(_capi.ft_stats)]
         lib.ft_fetch_frame.argtypes = [C.c_void_p, _capi.c_double_p]
+        lib.ft_render_rgba8.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32,
+                                        C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32, C.POINTER(C.c_uint8), C.POINTER(_capi.ft_stats)]
+        lib.ft_fetch_frame_rgba8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        lib.ft_render_enqueue_rgba8.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32, C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32]
+        lib.ft_host_alloc.restype = C.c_void_p
+        lib.ft_host_alloc.argtypes = [C.c_size_t]
+        lib.ft_host_free.restype = None
+        lib.ft_host_free.argtypes = [C.c_void_p]
         lib.ft_debug_closest.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, _capi.c_int32_p,
                                          _capi.c_double_p, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p]
         lib.ft_debug_blocked.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, _capi.c_int32_p]
+        lib.ft_debug_colour.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, C.c_int32, _capi.c_double_p]
         lib.ft_debug_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.ft_debug_slice.argtypes = [_capi.c_double_p] * 4 + [_capi.c_int32_p, _capi.c_double_p, _capi.c_int32_p]
         lib.ft_render_enqueue.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32, C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32]
@@ -224,11 +233,29 @@ class Context(SceneBuilder):
         self._check(self._lib.ft_fetch_frame(self._ctx, _capi.dptr(out)))
         return out
 
-    def render_enqueue(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None):
-        """ft_render_enqueue: queue a frame and return; `wait()` retires what is queued."""
+    def render_rgba8(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None, out=None, fetch=True):
+        """ft_render_rgba8: the frame as Image.write consumes it (Image.fs:35-44), quantised on the device.  Returns
+        (rgba[res_v, res_h, 4] uint8, stats dict); with fetch=False the bytes stay in HBM until `fetch_frame_rgba8`."""
+        jitter = np.zeros((1, 2)) if spp == 0 else _capi.as_f64(jitter, (spp, 2))
+        if fetch and out is None:
+            out = np.zeros((res_v, res_h, 4), dtype=np.uint8)
+        rects, n_rects = _capi.make_rects(tiles)
+        st = _capi.ft_stats()
+        rc = self._lib.ft_render_rgba8(self._ctx, C.byref(camera), res_h, res_v, spp, _capi.dptr(jitter), max_depth, int(seed), rects, n_rects,
+                                       out.ctypes.data_as(C.POINTER(C.c_uint8)) if fetch else None, C.byref(st))
+        self._check(rc)
+        return (out if fetch else None), st.as_dict()
+
+    def fetch_frame_rgba8(self, out):
+        self._check(self._lib.ft_fetch_frame_rgba8(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def render_enqueue(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None, rgba8=False):
+        """ft_render_enqueue[_rgba8]: queue a frame and return; `wait()` retires what is queued."""
         jitter = np.zeros((1, 2)) if spp == 0 else _capi.as_f64(jitter, (spp, 2))
         rects, n_rects = _capi.make_rects(tiles)
-        self._check(self._lib.ft_render_enqueue(self._ctx, C.byref(camera), res_h, res_v, spp, _capi.dptr(jitter), max_depth, int(seed), rects, n_rects))
+        fn = self._lib.ft_render_enqueue_rgba8 if rgba8 else self._lib.ft_render_enqueue
+        self._check(fn(self._ctx, C.byref(camera), res_h, res_v, spp, _capi.dptr(jitter), max_depth, int(seed), rects, n_rects))
 
     def wait(self):
         """ft_render_wait: statistics of the last queued frame; kernel_times() then holds the sums over all frames since the previous wait."""
@@ -240,7 +267,7 @@ class Context(SceneBuilder):
         ms = np.zeros(5)
         n = np.zeros(5, dtype=np.int32)
         self._check(self._lib.ft_get_kernel_times(self._ctx, _capi.dptr(ms), n.ctypes.data_as(_capi.c_int32_p)))
-        names = ["other", "closest", "shade", "blend", "primary"]   # "other": memsets, k_classify, statistics (and k_blend unless "timing" = 2)
+        names = ["other", "closest", "shade", "resolve", "primary"]   # "other": the fill, k_classify (and k_resolve unless "timing" = 2); "shade" includes k_tail
         return {k: {"ms": float(ms[i]), "launches": int(n[i])} for i, k in enumerate(names)}
 
     def closest(self, origins, dirs):
@@ -263,6 +290,14 @@ class Context(SceneBuilder):
         self._check(self._lib.ft_debug_blocked(self._ctx, _capi.dptr(o), _capi.dptr(d), _capi.dptr(m), o.shape[0], out.ctypes.data_as(_capi.c_int32_p)))
         return out
 
+    def colour_for_ray(self, origins, dirs, max_depth=MAX_DEPTH):
+        """Shading.getColourForRay (Shading.fs:131-139) for explicit rays, through the device path."""
+        o = _capi.as_f64(origins).reshape(-1, 3)
+        d = _capi.as_f64(dirs).reshape(-1, 3)
+        rgb = np.zeros((o.shape[0], 3))
+        self._check(self._lib.ft_debug_colour(self._ctx, _capi.dptr(o), _capi.dptr(d), o.shape[0], max_depth, _capi.dptr(rgb)))
+        return rgb
+
     def scene_info(self):
         out = (C.c_int64 * 12)()
         self._check(self._lib.ft_debug_scene_info(self._ctx, out))
@@ -275,10 +310,10 @@ def rays_handled_by(kernel, st):
     """Rays one frame's launches of `kernel` trace, from the frame's ft_stats (bench.py's roofline line)."""
     generated = st["rays_primary"] - st["rays_primary_culled"]
     if kernel == "primary":                                         # fused bounce 0: every generated primary ray + the shadow rays of its hits
-        return generated + st["rays_shadow_primary"] if "rays_shadow_primary" in st else generated + st["rays_shadow"]
-    if kernel == "closest":
+        return generated + st["rays_shadow_primary"]
+    if kernel == "closest":                                         # reflection rays of the staged bounces
         return st["rays_reflect"] - min(st["rays_reflect"], st["rays_tail"])
-    return st["rays_shadow"]
+    return st["rays_shadow"] - st["rays_shadow_primary"]            # shadow rays of bounces >= 1 (k_shade and k_tail)
 
 
 def debug_slice(p0, n, tri):

@@ -57,7 +57,7 @@ class ft_stats(C.Structure):
                 ("trace_kernel_ms", C.c_double), ("algorithmic_bytes", C.c_uint64), ("n_launches", C.c_int32),
                 ("n_chunks", C.c_int32), ("hits_total", C.c_uint64), ("algorithmic_bytes_closest", C.c_uint64),
                 ("algorithmic_bytes_shade", C.c_uint64), ("rays_tail", C.c_uint64), ("rays_primary_culled", C.c_uint64),
-                ("algorithmic_bytes_primary", C.c_uint64)]
+                ("algorithmic_bytes_primary", C.c_uint64), ("rays_shadow_primary", C.c_uint64), ("rays_reflect_primary", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -27,12 +28,17 @@ struct DeviceBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Stage indices of ft_get_kernel_times.
+enum { kStageOther = 0, kStageClosest = 1, kStageShade = 2, kStageResolve = 3, kStagePrimary = 4, kStages = 5 };
+// What a frame copies back when it retires: FrameCounters from `stats` to its end.
+struct FrameTail { ftk::RenderCounters stats[ftk::kStatStripes]; ftk::PixCount counts; uint32_t classify_ticket, classify_error, pad[2]; };
+static_assert(sizeof(FrameTail) == sizeof(ftk::FrameCounters) - offsetof(ftk::FrameCounters, stats), "FrameTail mirrors the end of FrameCounters");
+
 struct ft_context {
     std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
     bool host_only = false;
     int device = -1;
     int n_cu = 0;
-    uint32_t n_stat_slots = 0;      // one RenderCounters slot per wave of the largest persistent grid: n_cu x 8 blocks x 4 waves
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -44,24 +50,24 @@ struct ft_context {
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
     int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
-    bool fused_primary = true;      // bounce 0 through k_primary (one kernel) instead of k_closest + k_shade
     int64_t tail_rays = 262144;      // a bounce that starts with fewer rays is finished by k_tail (0 = never)
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_active_ids, d_active_pos, d_wide, d_mesh_wide, d_coarse, d_block_flags;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_block_pos, d_pos_block, d_wave_counts, d_wide, d_mesh_wide, d_coarse;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
-    DeviceBuf d_rays[2], d_hits, d_hit_list, d_touched, d_acc, d_out, d_pixels, d_jitter, d_cc, d_rc, d_dbg_in, d_dbg_out;
-    int64_t ray_capacity = 0;
+    DeviceBuf d_rays[2], d_hits, d_hit_list, d_acc, d_out, d_out8, d_pixels, d_jitter, d_fc, d_dbg_in, d_dbg_out;
+    uint32_t classify_epoch = 0;    // tags the entries k_classify's waves publish in d_wave_counts (cleared only when it wraps or the buffer grows)
+    int64_t ray_capacity = 0, acc_capacity = 0;
     // Per-frame host state.  Two slots, so that one frame can be queued while the previous one still runs (ft_render_enqueue).
     struct FrameSlot {
         std::vector<hipEvent_t> events; size_t events_used = 0;
         struct Span { hipEvent_t a, b; int kind; };
         std::vector<Span> spans;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
-        ftk::RenderCounters* h_rc = nullptr;    // pinned landing place of the frame's statistics
+        FrameTail* h_tail = nullptr;            // pinned landing place of the frame's statistic stripes and k_classify's error word
         bool pending = false;
-        uint64_t rays_primary = 0; int64_t n_pix_total = 0; int32_t spp = 0, n_launches = 0, n_chunks = 0, timing = 1; bool classify = false;
+        uint64_t rays_primary = 0; int64_t n_pix_total = 0; int32_t spp = 0, n_launches = 0, n_chunks = 0, timing = 1, format = 0; bool classify = false;
         std::chrono::steady_clock::time_point wall0;
     };
     FrameSlot slots[2];
@@ -72,12 +78,13 @@ struct ft_context {
     std::vector<uint32_t> pixels;
     std::vector<double> jitter_on_device;   // what d_jitter holds
     std::vector<ft_rect> pixel_rects;
-    bool pixels_whole = false, pixels_corner = false;
+    bool pixels_corner = false, pixels_tiled = false;   // the list holds corner-sampling pixels / is made of whole 8x8 tiles
+    int last_format = 0;            // 0: the last frame is FP64 RGB in d_out, 1: RGBA8 in d_out8
     DeviceBuf d_out_index;
     int64_t last_n_pix = 0;
     int32_t last_res_h = 0, last_res_v = 0;
-    double k_ms[5] = {0, 0, 0, 0, 0};
-    int32_t k_launches[5] = {0, 0, 0, 0, 0};
+    double k_ms[kStages] = {0, 0, 0, 0, 0};
+    int32_t k_launches[kStages] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -121,14 +128,14 @@ ftk::RayBuf ray_view(const DeviceBuf& b, int64_t cap) {
     return r;
 }
 
-int32_t ensure_frame_buffers(ft_context* c, int64_t cap) {
-    if (cap <= c->ray_capacity) return FT_OK;
+// Per-sample accumulators for every frame; ray / hit wavefront buffers only for scenes with reflective materials (bounce >= 1).
+int32_t ensure_frame_buffers(ft_context* c, int64_t cap, bool reflective) {
     int32_t rc;
+    if (cap > c->acc_capacity) { if ((rc = ensure(c, c->d_acc, (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
+    if (!reflective || cap <= c->ray_capacity) return FT_OK;
     for (int i = 0; i < 2; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_hits, (size_t)cap * 16)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_hit_list, (size_t)cap * 4)) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_touched, (size_t)cap)) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_acc, (size_t)cap * 24)) != FT_OK) return rc;
     c->ray_capacity = cap;
     return FT_OK;
 }
@@ -190,7 +197,6 @@ static int32_t create_single(int32_t device_id, int count, ft_context** out) {
     if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FT_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
-    c->n_stat_slots = (uint32_t)c->n_cu * 8u * (uint32_t)(ftk::kBlock / 64);   // every grid is n_cu x (at most 8) blocks (clamp_blocks, Lg)
     *out = c;
     return FT_OK;
 }
@@ -231,11 +237,11 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_active_ids, &c->d_active_pos, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_block_flags, &c->d_out_index,
-                             &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_touched, &c->d_acc, &c->d_out, &c->d_pixels, &c->d_jitter, &c->d_cc, &c->d_rc,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos, &c->d_pos_block, &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
+                             &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
-        for (auto& f : c->slots) { if (f.h_rc) { (void)hipHostFree(f.h_rc); f.h_rc = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
+        for (auto& f : c->slots) { if (f.h_tail) { (void)hipHostFree(f.h_tail); f.h_tail = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -250,7 +256,6 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "coherent_waves")) { c->coherent_waves = value != 0; c->dev_scene.coherent_waves = value != 0 ? 1 : 0; for (ft_context* p : c->peers) { p->coherent_waves = value != 0; p->dev_scene.coherent_waves = c->dev_scene.coherent_waves; } return FT_OK; }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
-    if (!std::strcmp(key, "fused_primary")) { c->fused_primary = value != 0; for (ft_context* p : c->peers) p->fused_primary = value != 0; return FT_OK; }
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
     if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
@@ -393,8 +398,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_mesh_wide, f.mesh_wide)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_coarse, f.coarse_boxes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_cc, sizeof(ftk::ChunkCounters))) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_rc, sizeof(ftk::RenderCounters) * ((size_t)c->n_stat_slots + 2))) != FT_OK) return rc;   // + one slot's worth for the frame's PixCount
+    if ((rc = ensure(c, c->d_fc, sizeof(ftk::FrameCounters))) != FT_OK) return rc;
     FT_HIP(c, hipStreamSynchronize(c->stream));
     ftk::DevScene& S = c->dev_scene;
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
@@ -416,56 +420,81 @@ static int32_t upload_scene(ft_context* c) {
     return FT_OK;
 }
 
-// Copy the pixels of the last ft_render from HBM into the caller's frame (row 0 = top, Image.fs:39).
-static int32_t fetch_single(ft_context* c, double* out_rgb);
-
-int32_t ft_fetch_frame(ft_context* c, double* out_rgb) {
-    if (!c || !out_rgb) return FT_ERR_INVALID;
-    if (!need_device(c)) return FT_ERR_NO_DEVICE;
-    bool any = false;
-    int32_t rc = FT_OK;
-    if (c->last_n_pix > 0) { rc = fetch_single(c, out_rgb); any = true; }
-    for (ft_context* p : c->peers) {                                // every device copies its own bands into the caller's frame
-        if (rc != FT_OK || p->last_n_pix <= 0) continue;
-        rc = fetch_single(p, out_rgb); any = true;
-        if (rc != FT_OK) c->err = p->err;
-    }
-    if (!any) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
-    return rc;
-}
-
-static int32_t fetch_single(ft_context* c, double* out_rgb) {
+// ------------------------------------------------------------------------------------------ frames out of HBM
+// The device keeps the last frame in FRAME layout (row 0 = top, Image.fs:39) whatever the tiles were: d_out as FP64 RGB or d_out8 as
+// Image.write's RGBA8 bytes (Image.fs:36).  Fetching copies the rendered rects - whole rows as one copy, narrower rects as a 2D copy -
+// straight into the caller's frame; nothing is gathered or scattered on the host.
+static int32_t fetch_single(ft_context* c, void* out, int format) {
     if (c->last_n_pix <= 0) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
+    if (format != c->last_format) { c->err = format == 1 ? "the last frame was rendered as FP64 RGB (ft_render): no RGBA8 frame to fetch" : "the last frame was rendered as RGBA8 (ft_render_rgba8): no FP64 frame to fetch"; return FT_ERR_STATE; }
     FT_HIP(c, hipSetDevice(c->device));
     FT_HIP(c, hipStreamSynchronize(c->stream));                     // frames queued with ft_render_enqueue may still be running (the stream is non-blocking)
-    const int64_t n = c->last_n_pix;
-    if (c->pixels_whole) {                                         // k_blend wrote the frame in place
-        FT_HIP(c, hipMemcpy(out_rgb, c->d_out.p, (size_t)c->last_res_h * c->last_res_v * 24, hipMemcpyDeviceToHost));
-    } else {
-        std::vector<double> packed((size_t)n * 3);
-        FT_HIP(c, hipMemcpy(packed.data(), c->d_out.p, packed.size() * 8, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; ++i) std::memcpy(out_rgb + 3 * (size_t)c->pixels[(size_t)i], &packed[3 * (size_t)i], 24);
+    const size_t px = format == 1 ? 4 : 24, pitch = (size_t)c->last_res_h * px;
+    const char* src = static_cast<const char*>(format == 1 ? c->d_out8.p : c->d_out.p);
+    char* dst = static_cast<char*>(out);
+    for (size_t k = 0; k < c->pixel_rects.size();) {
+        const ft_rect r = c->pixel_rects[k];
+        if (r.x0 == 0 && r.w == c->last_res_h) {                    // whole rows; vertically adjacent rects go out as one copy
+            int rows = r.h;
+            size_t k2 = k + 1;
+            while (k2 < c->pixel_rects.size() && c->pixel_rects[k2].x0 == 0 && c->pixel_rects[k2].w == r.w && c->pixel_rects[k2].y0 == r.y0 + rows) { rows += c->pixel_rects[k2].h; ++k2; }
+            FT_HIP(c, hipMemcpy(dst + (size_t)r.y0 * pitch, src + (size_t)r.y0 * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost));
+            k = k2;
+        } else {
+            const size_t off = (size_t)r.y0 * pitch + (size_t)r.x0 * px;
+            FT_HIP(c, hipMemcpy2D(dst + off, pitch, src + off, pitch, (size_t)r.w * px, (size_t)r.h, hipMemcpyDeviceToHost));
+            ++k;
+        }
     }
     return FT_OK;
 }
 
+static int32_t fetch_all(ft_context* c, void* out, int format) {
+    if (!c || !out) return FT_ERR_INVALID;
+    if (!need_device(c)) return FT_ERR_NO_DEVICE;
+    std::vector<ft_context*> devs{c};
+    devs.insert(devs.end(), c->peers.begin(), c->peers.end());
+    std::vector<ft_context*> with;
+    for (ft_context* d : devs) if (d->last_n_pix > 0) with.push_back(d);
+    if (with.empty()) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
+    if (with.size() == 1) { const int32_t rc = fetch_single(with[0], out, format); if (rc != FT_OK && with[0] != c) c->err = with[0]->err; return rc; }
+    std::vector<int32_t> rcs(with.size(), FT_OK);                   // every device copies its own bands into the caller's frame, all at once
+    std::vector<std::thread> threads;
+    for (size_t d = 0; d < with.size(); ++d) threads.emplace_back([&, d] { rcs[d] = fetch_single(with[d], out, format); });
+    for (auto& t : threads) t.join();
+    for (size_t d = 0; d < with.size(); ++d) if (rcs[d] != FT_OK) { if (with[d] != c) c->err = with[d]->err; return rcs[d]; }
+    return FT_OK;
+}
+int32_t ft_fetch_frame(ft_context* c, double* out_rgb) { return fetch_all(c, out_rgb, 0); }
+int32_t ft_fetch_frame_rgba8(ft_context* c, uint8_t* out_rgba) { return fetch_all(c, out_rgba, 1); }
+
+/* Page-locked host memory for frames (hipHostMalloc): a D2H copy into it is one DMA at link rate, without the runtime's staging. */
+void* ft_host_alloc(size_t bytes) { void* p = nullptr; return (bytes && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) ? p : nullptr; }
+void ft_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 // ------------------------------------------------------------------------------------------ render
-static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats, bool defer = false);
+struct RenderRequest {
+    const ft_camera* cam; int32_t res_h, res_v, spp; const double* jitter_xy; int32_t max_depth; uint64_t seed;
+    const ft_rect* tiles; int32_t n_tiles; int format;               // 0: FP64 RGB frame, 1: RGBA8 frame
+};
+static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, ft_stats* stats, bool defer);
 static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& f, ft_stats* stats);
 static int32_t retire_pending(ft_context* c, ft_stats* stats);
-
-static int32_t render_frame(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                            int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats);
+static int32_t render_frame(ft_context* c, const RenderRequest& q, void* out, ft_stats* stats, bool defer);
 
 static int32_t with_growing_hit_lists(ft_context* c, const std::function<int32_t()>& run) {
     // Frames still queued by ft_render_enqueue are retired first, so that an overflow of one of THEM is reported as what it is
     // (queued frames are not rendered again) instead of being taken for this call's.
-    if (!c->host_only && (c->slots[0].pending || c->slots[1].pending)) {
-        if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return FT_ERR_NO_DEVICE; }
-        const int32_t prc = retire_pending(c, nullptr);
-        c->accum_open = false;
-        if (prc != FT_OK) return prc;
+    if (!c->host_only) {
+        std::vector<ft_context*> devs{c};
+        devs.insert(devs.end(), c->peers.begin(), c->peers.end());
+        for (ft_context* d : devs) {
+            if (!d->slots[0].pending && !d->slots[1].pending) continue;
+            if (hipSetDevice(d->device) != hipSuccess) { c->err = "hipSetDevice failed"; return FT_ERR_NO_DEVICE; }
+            const int32_t prc = retire_pending(d, nullptr);
+            d->accum_open = false;
+            if (prc != FT_OK) { if (d != c) c->err = d->err; return prc; }
+        }
     }
     int32_t rc = run();
     while (rc == FT_ERR_OVERFLOW && c->csg_auto_grow && c->graph.csg_mesh_capacity < 255) {
@@ -489,54 +518,77 @@ static int32_t with_growing_hit_lists(ft_context* c, const std::function<int32_t
 int32_t ft_render(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                   int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
     if (!c) return FT_ERR_INVALID;
-    return with_growing_hit_lists(c, [&] { return render_frame(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats); });
+    const RenderRequest q{cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, 0};
+    return with_growing_hit_lists(c, [&] { return render_frame(c, q, out_rgb, stats, false); });
+}
+int32_t ft_render_rgba8(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                        int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, uint8_t* out_rgba, ft_stats* stats) {
+    if (!c) return FT_ERR_INVALID;
+    const RenderRequest q{cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, 1};
+    return with_growing_hit_lists(c, [&] { return render_frame(c, q, out_rgba, stats, false); });
 }
 
-static int32_t render_frame(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                            int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats) {
-    if (c->peers.empty() || c->host_only) return render_single(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, out_rgb, stats);
-    if (!cam || res_h < 2 || res_v < 2 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
-    if (!c->committed) { c->err = "scene not committed (ft_scene_commit)"; return FT_ERR_STATE; }
-    // Image-tile partition over the devices: 8-row bands of every requested rect, dealt round-robin.
-    const auto wall0 = std::chrono::steady_clock::now();
-    std::vector<ft_context*> devs{c};
-    devs.insert(devs.end(), c->peers.begin(), c->peers.end());
-    std::vector<std::vector<ft_rect>> share(devs.size());
-    std::vector<ft_rect> whole_frame{ft_rect{0, 0, res_h, res_v}};
-    const ft_rect* src = tiles ? tiles : whole_frame.data();
-    const int n_src = tiles ? n_tiles : 1;
+static void add_stats(ft_stats* t, const ft_stats& s) {
+    t->rays_primary += s.rays_primary; t->rays_shadow += s.rays_shadow; t->rays_reflect += s.rays_reflect; t->rays_traced += s.rays_traced;
+    t->rays_reference_equivalent += s.rays_reference_equivalent; t->hits_primary += s.hits_primary; t->csg_overflow += s.csg_overflow;
+    t->kernel_ms = std::max(t->kernel_ms, s.kernel_ms); t->trace_kernel_ms = std::max(t->trace_kernel_ms, s.trace_kernel_ms);
+    t->algorithmic_bytes += s.algorithmic_bytes; t->hits_total += s.hits_total; t->algorithmic_bytes_closest += s.algorithmic_bytes_closest;
+    t->algorithmic_bytes_shade += s.algorithmic_bytes_shade; t->algorithmic_bytes_primary += s.algorithmic_bytes_primary; t->n_launches += s.n_launches; t->n_chunks += s.n_chunks;
+    t->rays_tail += s.rays_tail; t->rays_primary_culled += s.rays_primary_culled; t->rays_shadow_primary += s.rays_shadow_primary; t->rays_reflect_primary += s.rays_reflect_primary;
+}
+
+// Image-tile partition of a region over the devices of a context: 8-row bands of every requested rect, dealt round-robin.
+static std::vector<std::vector<ft_rect>> band_shares(const RenderRequest& q, size_t n_devs) {
+    std::vector<std::vector<ft_rect>> share(n_devs);
+    const ft_rect whole_frame{0, 0, q.res_h, q.res_v};
+    const ft_rect* src = q.tiles ? q.tiles : &whole_frame;
+    const int n_src = q.tiles ? q.n_tiles : 1;
     size_t band = 0;
     for (int k = 0; k < n_src; ++k)
         for (int y = src[k].y0; y < src[k].y0 + src[k].h; y += 8, ++band)
-            share[band % devs.size()].push_back(ft_rect{src[k].x0, y, src[k].w, std::min(8, src[k].y0 + src[k].h - y)});
+            share[band % n_devs].push_back(ft_rect{src[k].x0, y, src[k].w, std::min(8, src[k].y0 + src[k].h - y)});
+    return share;
+}
+
+static int32_t render_frame(ft_context* c, const RenderRequest& q, void* out, ft_stats* stats, bool defer) {
+    if (c->peers.empty() || c->host_only) return render_single(c, q, out, stats, defer);
+    if (!q.cam || q.res_h < 2 || q.res_v < 2 || (q.tiles && q.n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
+    if (!c->committed) { c->err = "scene not committed (ft_scene_commit)"; return FT_ERR_STATE; }
+    const auto wall0 = std::chrono::steady_clock::now();
+    std::vector<ft_context*> devs{c};
+    devs.insert(devs.end(), c->peers.begin(), c->peers.end());
+    const std::vector<std::vector<ft_rect>> share = band_shares(q, devs.size());
     std::vector<int32_t> rcs(devs.size(), FT_OK);
     std::vector<ft_stats> sts(devs.size());
+    // One host thread per device: each queues its bands' frame on its own stream, waits for it and copies its bands straight into the
+    // caller's frame (whole rows: one contiguous copy per band).  No device waits for another; the bands meet in `out`.
     std::vector<std::thread> threads;
     for (size_t d = 0; d < devs.size(); ++d)
         threads.emplace_back([&, d] {
             std::memset(&sts[d], 0, sizeof(ft_stats));
             if (share[d].empty()) { devs[d]->last_n_pix = 0; return; }
-            rcs[d] = render_single(devs[d], cam, res_h, res_v, spp, jitter_xy, max_depth, seed, share[d].data(), (int32_t)share[d].size(), out_rgb, &sts[d]);
+            RenderRequest qd = q;
+            qd.tiles = share[d].data(); qd.n_tiles = (int32_t)share[d].size();
+            rcs[d] = render_single(devs[d], qd, out, &sts[d], defer);
         });
     for (auto& t : threads) t.join();
     for (size_t d = 0; d < devs.size(); ++d) if (rcs[d] != FT_OK) { if (d) c->err = devs[d]->err; return rcs[d]; }
-    if (stats) {
+    if (stats && !defer) {
         std::memset(stats, 0, sizeof *stats);
-        for (auto& s : sts) {
-            stats->rays_primary += s.rays_primary; stats->rays_shadow += s.rays_shadow; stats->rays_reflect += s.rays_reflect; stats->rays_traced += s.rays_traced;
-            stats->rays_reference_equivalent += s.rays_reference_equivalent; stats->hits_primary += s.hits_primary; stats->csg_overflow += s.csg_overflow;
-            stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms); stats->trace_kernel_ms = std::max(stats->trace_kernel_ms, s.trace_kernel_ms);
-            stats->algorithmic_bytes += s.algorithmic_bytes; stats->hits_total += s.hits_total; stats->algorithmic_bytes_closest += s.algorithmic_bytes_closest;
-            stats->algorithmic_bytes_shade += s.algorithmic_bytes_shade; stats->n_launches += s.n_launches; stats->n_chunks += s.n_chunks;
-        }
+        for (auto& s : sts) add_stats(stats, s);
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
     return FT_OK;
 }
 
-static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
-                             int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, double* out_rgb, ft_stats* stats, bool defer) {
+static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, ft_stats* stats, bool defer) {
     if (!c) return FT_ERR_INVALID;
+    const ft_camera* cam = q.cam;
+    const int32_t res_h = q.res_h, res_v = q.res_v, max_depth = q.max_depth, n_tiles = q.n_tiles;
+    const ft_rect* tiles = q.tiles;
+    const double* jitter_xy = q.jitter_xy;
+    const uint64_t seed = q.seed;
+    int32_t spp = q.spp;
     if (!cam || res_h < 2 || res_v < 2 || spp < 0 || (spp > 0 && !jitter_xy) || max_depth < 0 || (tiles && n_tiles < 1)) { c->err = "bad ft_render argument"; return FT_ERR_INVALID; }
     if (max_depth > ftk::kMaxBounce) { c->err = "max_depth above 16"; return FT_ERR_UNSUPPORTED; }
     if ((int64_t)res_h * res_v > (int64_t)0x7FFFFFFF) { c->err = "resolution too large"; return FT_ERR_INVALID; }
@@ -561,7 +613,7 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         if (r.y0 + r.h > res_v) r.h = res_v - r.y0;
         if (r.w > 0 && r.h > 0) rects.push_back(r);
     }
-    const bool same_list = !corner && !c->pixels_corner && c->last_n_pix > 0 && c->last_res_h == res_h && c->last_res_v == res_v && c->pixels_whole == whole &&
+    const bool same_list = !corner && !c->pixels_corner && c->last_n_pix > 0 && c->last_res_h == res_h && c->last_res_v == res_v &&
                            c->pixel_rects.size() == rects.size() && (rects.empty() || std::memcmp(c->pixel_rects.data(), rects.data(), rects.size() * sizeof(ft_rect)) == 0);
     struct Job { uint32_t id_base, n_ids, w, h, out_base, n_out; };
     std::vector<Job> jobs;
@@ -582,19 +634,21 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
                 jobs.push_back(j);
             }
         }
-        c->pixel_rects = rects; c->pixels_whole = whole; c->pixels_corner = true; c->last_n_pix = 0;
+        c->pixel_rects = rects; c->pixels_corner = true; c->pixels_tiled = false; c->last_n_pix = 0;
     } else if (!same_list) {
         std::vector<uint32_t>& px = c->pixels;
         px.clear();
+        bool tiled = true;
         for (const ft_rect& r : rects) {
             if (r.w % 8 == 0 && r.h % 8 == 0) {
                 for (int ty = 0; ty < r.h; ty += 8) for (int tx = 0; tx < r.w; tx += 8)
                     for (int iy = 0; iy < 8; ++iy) for (int ix = 0; ix < 8; ++ix) px.push_back((uint32_t)((r.y0 + ty + iy) * res_h + r.x0 + tx + ix));
             } else {
+                tiled = false;
                 for (int y = r.y0; y < r.y0 + r.h; ++y) for (int x = r.x0; x < r.x0 + r.w; ++x) px.push_back((uint32_t)(y * res_h + x));
             }
         }
-        c->pixel_rects = rects; c->pixels_whole = whole; c->pixels_corner = false; c->last_n_pix = 0;
+        c->pixel_rects = rects; c->pixels_corner = false; c->pixels_tiled = tiled; c->last_n_pix = 0;
     }
     const std::vector<uint32_t>& pixels = c->pixels;
     const int64_t n_pix_total = (int64_t)pixels.size();
@@ -602,19 +656,19 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     if (n_pix_total == 0) return FT_OK;
 
     int32_t rc;
-    // k_classify applies to pinhole cameras over whole 64-pixel blocks and scenes in which every top-level item is bounded (with a
-    // ground plane in view an exact plane test does find the sky blocks - 20 % of night-house - but the denser first chunk makes
-    // k_shade slower than the blocks save).  A classified frame's chunks are windows of its ACTIVE pixel list, usually a fraction
-    // of the frame: they are twice as wide (measured at 1080p x 16: bunny 0.58 -> 0.55 ms, hollow-sphere 6.1 -> 5.8, sample 1.64 ->
-    // 1.50; the unclassified night-house loses 14 % at that width and keeps the narrow one).
     // k_classify bounds every sample of a pixel by a square of +-extent pixels around its centre.  The reference's offsets lie in the
     // unit disc (Jitter.fs:15-21) but the pattern is the caller's: the square follows the pattern, and a pattern with a non-finite
     // or absurd offset turns classification off instead of bounding nothing.
     double jitter_extent = 1.0;
     bool jitter_bounded = true;
     if (!corner) for (size_t k = 0; k < 2 * (size_t)spp; ++k) { const double v = jitter_xy[k]; if (!(std::fabs(v) <= 64.0)) jitter_bounded = false; else jitter_extent = std::max(jitter_extent, std::fabs(v)); }
-    const bool classifiable = c->classify_pixels && jitter_bounded && !corner && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && !c->flat.unbounded;
-    const int64_t chunk_budget = classifiable ? 2 * c->chunk_samples : c->chunk_samples;
+    // k_classify applies to pinhole cameras over pixel lists made of 8x8 tiles and scenes in which every top-level item is bounded (with
+    // a ground plane in view an exact plane test does find the sky blocks - 20 % of night-house - but the denser first chunk makes the
+    // shading slower than the blocks save).  A classified frame's chunks are windows of its ACTIVE pixel list, usually a fraction
+    // of the frame: they are twice as wide (measured at 1080p x 16 in round 1: bunny 0.58 -> 0.55 ms, hollow-sphere 6.1 -> 5.8, sample
+    // 1.64 -> 1.50; the unclassified night-house loses 14 % at that width and keeps the narrow one).
+    const bool classify = c->classify_pixels && jitter_bounded && !corner && c->pixels_tiled && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && !c->flat.unbounded;
+    const int64_t chunk_budget = classify ? 2 * c->chunk_samples : c->chunk_samples;
     int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, chunk_budget / spp));
     if (pix_per_chunk > 64) {
         // equal chunks rather than full ones and a remainder: a short last chunk is all latency (measured on night-house at
@@ -631,8 +685,11 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         jobs.push_back(Job{(uint32_t)p0, n, 0, 0, (uint32_t)p0, n});
     }
     if (cap > 0x7FFFFFFFll) { c->err = "chunk too large"; return FT_ERR_INVALID; }
-    if ((rc = ensure_frame_buffers(c, cap)) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_out, (size_t)(whole ? (int64_t)res_h * res_v : n_pix_total) * 24)) != FT_OK) return rc;
+    const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned
+    if ((rc = ensure_frame_buffers(c, cap, last_bounce > 0)) != FT_OK) return rc;
+    const size_t frame_pixels = (size_t)res_h * (size_t)res_v;
+    if (q.format == 1) { if ((rc = ensure(c, c->d_out8, frame_pixels * 4)) != FT_OK) return rc; }
+    else if ((rc = ensure(c, c->d_out, frame_pixels * 24)) != FT_OK) return rc;
     if (corner) {
         if ((rc = upload(c, c->d_pixels, corner_ids)) != FT_OK) return rc;
         if ((rc = upload(c, c->d_out_index, pixels)) != FT_OK) return rc;
@@ -644,53 +701,53 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
         c->jitter_on_device = jit;                                 // (the copy source outlives this call)
         if ((rc = upload(c, c->d_jitter, c->jitter_on_device)) != FT_OK) return rc;
     }
-    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters) * ((size_t)c->n_stat_slots + 2), c->stream));
-
-    bool classify = classifiable && pix_per_chunk % 64 == 0;
-    for (const Job& j : jobs) if (j.n_ids % 64u) classify = false;
+    ftk::ClassifyOut cls{};
     if (classify) {
-        if ((rc = ensure(c, c->d_active_ids, (size_t)n_pix_total * 4)) != FT_OK) return rc;
-        if ((rc = ensure(c, c->d_active_pos, (size_t)n_pix_total * 4)) != FT_OK) return rc;
-        const size_t n_blocks = (size_t)n_pix_total / 64, n_seg = (n_blocks + ftk::kClassifySegmentBlocks - 1) / ftk::kClassifySegmentBlocks;
-        if ((rc = ensure(c, c->d_block_flags, n_seg * 4 + n_blocks)) != FT_OK) return rc;             // segment counts, then one byte per block
-        FT_HIP(c, hipMemsetAsync(c->d_block_flags.p, 0, n_seg * 4, c->stream));
+        const size_t n_blocks = (size_t)n_pix_total / 64, n_waves = (n_blocks + 255) / 256;   // one word per k_classify workgroup
+        if ((rc = ensure(c, c->d_block_pos, n_blocks * 4)) != FT_OK) return rc;
+        if ((rc = ensure(c, c->d_pos_block, n_blocks * 4)) != FT_OK) return rc;
+        if (c->d_wave_counts.bytes < n_waves * 4 || c->classify_epoch >= 0x3FFFFEu) {   // entries are tagged with the frame's epoch and never cleared in between
+            if ((rc = ensure(c, c->d_wave_counts, std::max<size_t>(n_waves * 4, 4096))) != FT_OK) return rc;
+            FT_HIP(c, hipMemsetAsync(c->d_wave_counts.p, 0, c->d_wave_counts.bytes, c->stream));
+            c->classify_epoch = 0;
+        }
+        cls = ftk::ClassifyOut{c->d_block_pos.as<int32_t>(), c->d_pos_block.as<uint32_t>(), c->d_wave_counts.as<uint32_t>()};
     }
+    auto* fc = c->d_fc.as<ftk::FrameCounters>();
+    FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream));   // the ONE fill of a frame: chunk counters, statistic stripes, list length, ticket
+
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
     int variant = 0;
     for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;   // FANCY
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
     if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
+    ftk::Launch Lp{c->stream, c->n_cu * ftk::occupancy_blocks_primary(lds, variant), lds, variant};
     ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds, variant), lds, variant};
     ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds, variant), lds, variant};
     ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_tail(lds, variant), lds, variant};
-    ftk::Launch Lp{c->stream, c->n_cu * ftk::occupancy_blocks_primary(lds, variant), lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
-    const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
     ftk::HitBuf hb{c->d_hits.as<double>(), reinterpret_cast<uint32_t*>(c->d_hits.as<double>() + c->ray_capacity),
                    reinterpret_cast<uint32_t*>(c->d_hits.as<double>() + c->ray_capacity) + c->ray_capacity};
-    auto* cc = c->d_cc.as<ftk::ChunkCounters>();
-    auto* rcount = c->d_rc.as<ftk::RenderCounters>();
 
     // A blocking call retires whatever is in flight first; a deferred one only the frame whose slot it is about to reuse.
-    if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < 5; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
+    if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < kStages; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
     ft_context::FrameSlot& F = c->slots[c->slot_turn];
     if (F.pending) { int32_t prc = retire_frame(c, F, nullptr); if (prc != FT_OK) return prc; }
-    if (defer && !c->accum_open) { for (int k = 0; k < 5; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = true; }
+    if (defer && !c->accum_open) { for (int k = 0; k < kStages; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = true; }
     F.events_used = 0; F.spans.clear();
     auto& spans = F.spans;
     using Span = ft_context::FrameSlot::Span;
-    // HIP events between stages.  An event between two dependent kernels costs about 6 us of stream time (measured: 0.2 us
-    // between k_classify and k_classify_finish, which have none between them), so by default ("timing" = 1) only the two
-    // kernels that matter, k_closest and k_shade, are bracketed; 2 brackets every stage, 0 only the frame.
+    // HIP events between stages.  An event between two dependent kernels costs about 6 us of stream time, so by default ("timing"
+    // = 1) only the kernels that trace rays (k_primary, k_closest, k_shade, k_tail) are bracketed; 2 brackets every stage, 0 only the frame.
     hipEvent_t ev0 = next_event(F), ev1 = nullptr;
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     hipEvent_t boundary = ev0;
     bool boundary_fresh = true;                                    // `boundary` was recorded right before the next launch
     const int timing = c->timing;
     auto timed = [&](int kind, auto&& fn) {
-        const bool bracket = timing >= 2 || (timing == 1 && (kind == 1 || kind == 2 || kind == 4));
+        const bool bracket = timing >= 2 || (timing == 1 && (kind == kStageClosest || kind == kStageShade || kind == kStagePrimary));
         if (bracket && !boundary_fresh) { boundary = next_event(F); if (boundary) (void)hipEventRecord(boundary, c->stream); }
         fn();
         if (!bracket) { boundary_fresh = false; return; }
@@ -702,63 +759,61 @@ static int32_t render_single(ft_context* c, const ft_camera* cam, int32_t res_h,
     int n_chunks = 0, n_launches = 0;
     // The whole frame is classified once; the chunks then take consecutive windows of the frame's ACTIVE pixel list, so a sparse
     // frame is one chunk of real work and launches that find their window empty return at once.
-    ftk::PixCount* const frame_counts = reinterpret_cast<ftk::PixCount*>(rcount + c->n_stat_slots + 1);
     if (classify) {
         const ftk::Primary all{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), 0u, (uint32_t)n_pix_total, spp, (uint32_t)res_h,
-                               (unsigned long long)seed, 1.0 / (double)n_pix_total, 1.0 / (double)res_h, nullptr};
-        const size_t n_seg = ((size_t)n_pix_total / 64 + ftk::kClassifySegmentBlocks - 1) / ftk::kClassifySegmentBlocks;
-        timed(0, [&] { ftk::launch_classify(Lg, c->dev_scene, all, c->d_block_flags.as<uint8_t>() + n_seg * 4, c->d_block_flags.as<uint32_t>(), c->d_active_ids.as<uint32_t>(),
-                                            c->d_active_pos.as<uint32_t>(), frame_counts, c->d_out.as<double>(), whole ? 1 : 0, jitter_extent, rcount); });
-        n_launches += 2;
+                               (unsigned long long)seed, 1.0 / (double)n_pix_total, 1.0 / (double)res_h, nullptr, nullptr};
+        const uint32_t epoch = ++c->classify_epoch;
+        timed(kStageOther, [&] { ftk::launch_classify(Lg, c->dev_scene, all, cls, jitter_extent, epoch, fc); });
+        ++n_launches;
     }
+    double* const out_rgb = q.format == 1 ? nullptr : c->d_out.as<double>();
+    uint8_t* const out_rgba = q.format == 1 ? c->d_out8.as<uint8_t>() : nullptr;
     for (const Job& job : jobs) {
-        ++n_chunks;
         const uint32_t n_pix = job.n_ids;
         const uint32_t n_samples = n_pix * (uint32_t)spp;
-        timed(0, [&] { (void)hipMemsetAsync(cc, 0, sizeof(ftk::ChunkCounters), c->stream); });
+        if (n_chunks > 0) timed(kStageOther, [&] { (void)hipMemsetAsync(&fc->cc, 0, sizeof(ftk::ChunkCounters), c->stream); });
+        ++n_chunks;
         ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
                          (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
-                         1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h), nullptr};
-        double* const chunk_out = whole ? c->d_out.as<double>() : c->d_out.as<double>() + 3 * (size_t)job.out_base;
-        if (classify) { gen.pixel_ids = c->d_active_ids.as<uint32_t>(); gen.counts = frame_counts; }   // pix_base = job.id_base: the window's start
-        for (int b = 0; b <= last_bounce; ++b) {
-            if (b == 0 && c->fused_primary) {
-                timed(4, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, max_depth, cc, rcount); });
-                ++n_launches;
-                continue;
-            }
-            timed(1, [&] { ftk::launch_closest(Lc, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), c->d_touched.as<uint8_t>(), b, (uint32_t)c->tail_rays, cc, rcount); });
-            timed(2, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, cc, rcount); });
+                         1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h), nullptr, nullptr};
+        if (classify) { gen.counts = &fc->counts; gen.block_map = c->d_pos_block.as<uint32_t>(); }   // pix_base = job.id_base: the window's start in the active list
+        timed(kStagePrimary, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], c->d_acc.as<double>(), n_samples, max_depth, fc); });
+        ++n_launches;
+        for (int b = 1; b <= last_bounce; ++b) {
+            timed(kStageClosest, [&] { ftk::launch_closest(Lc, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), b, (uint32_t)c->tail_rays, fc); });
+            timed(kStageShade, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, fc); });
             n_launches += 2;
         }
         if (last_bounce >= 1 && c->tail_rays > 0) {
-            timed(2, [&] { ftk::launch_tail(Lt, c->dev_scene, gen, rb[0], rb[1], c->d_acc.as<double>(), n_samples, max_depth, (uint32_t)c->tail_rays, cc, rcount); });
+            timed(kStageShade, [&] { ftk::launch_tail(Lt, c->dev_scene, gen, rb[0], rb[1], c->d_acc.as<double>(), n_samples, max_depth, (uint32_t)c->tail_rays, fc); });
             ++n_launches;
         }
-        const uint32_t* out_index = !whole ? nullptr : (corner ? c->d_out_index.as<uint32_t>() : c->d_pixels.as<uint32_t>()) + job.out_base;
-        double* out_ptr = chunk_out;
-        if (classify) { out_index = (whole ? c->d_active_ids.as<uint32_t>() : c->d_active_pos.as<uint32_t>()) + job.id_base; out_ptr = c->d_out.as<double>(); }
-        if (corner) timed(3, [&] { ftk::launch_blend_corner(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, job.w, job.h, out_index, out_ptr); });
-        else timed(3, [&] { ftk::launch_blend(Lg, c->d_acc.as<double>(), c->d_touched.as<uint8_t>(), n_samples, n_pix, classify ? frame_counts : nullptr, job.id_base, spp, out_index, out_ptr); });
+        if (corner) timed(kStageResolve, [&] { ftk::launch_resolve_corner(Lg, c->d_acc.as<double>(), n_samples, job.w, job.h, c->d_out_index.as<uint32_t>() + job.out_base, out_rgb, out_rgba); });
+        else {
+            ftk::ResolveArgs ra{c->d_acc.as<double>(), n_samples, classify ? &fc->counts : nullptr, job.id_base, n_pix, spp,
+                                classify ? c->d_pos_block.as<uint32_t>() : nullptr, (classify && n_chunks == 1) ? c->d_block_pos.as<int32_t>() : nullptr,
+                                (uint32_t)(n_pix_total / 64), c->d_pixels.as<uint32_t>(), out_rgb, out_rgba};
+            timed(kStageResolve, [&] { ftk::launch_resolve(Lg, ra); });
+        }
         ++n_launches;
     }
-    timed(0, [&] { ftk::launch_reduce_stats(Lg, rcount, c->n_stat_slots); });
     if (boundary_fresh) ev1 = boundary;
     else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
     FT_HIP(c, hipGetLastError());
-    if (!F.h_rc) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_rc), sizeof(ftk::RenderCounters), hipHostMallocDefault));
-    FT_HIP(c, hipMemcpyAsync(F.h_rc, c->d_rc.p, sizeof(ftk::RenderCounters), hipMemcpyDeviceToHost, c->stream));   // rides the frame's one wait
+    if (!F.h_tail) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_tail), sizeof(FrameTail), hipHostMallocDefault));
+    FT_HIP(c, hipMemcpyAsync(F.h_tail, &fc->stats[0], sizeof(FrameTail), hipMemcpyDeviceToHost, c->stream));   // rides the frame's one wait
     F.done = next_event(F);
     if (F.done) FT_HIP(c, hipEventRecord(F.done, c->stream));
     F.ev0 = ev0; F.ev1 = ev1; F.pending = true; F.wall0 = wall0; F.timing = timing;
     F.rays_primary = 0; for (auto& j : jobs) F.rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;
-    F.n_pix_total = n_pix_total; F.spp = spp; F.n_launches = n_launches; F.n_chunks = n_chunks; F.classify = classify;
-    c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v;
+    F.n_pix_total = n_pix_total; F.spp = spp; F.n_launches = n_launches; F.n_chunks = n_chunks; F.classify = classify; F.format = q.format;
+    c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v; c->last_format = q.format;
     c->slot_turn ^= 1;
     if (defer) return FT_OK;                                       // ft_render_enqueue: the frame is retired by a later call
     int32_t rrc = retire_frame(c, F, stats);
     if (rrc != FT_OK) return rrc;
-    if (out_rgb) { int32_t frc = fetch_single(c, out_rgb); if (frc != FT_OK) return frc; }   // out_rgb == NULL: the frame stays in HBM
+    if (out) { int32_t frc = fetch_single(c, out, q.format); if (frc != FT_OK) return frc; }   // out == NULL: the frame stays in HBM
+    if (stats) stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return FT_OK;
 }
 
@@ -767,19 +822,28 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
     if (!F.pending) return FT_OK;
     F.pending = false;
     if (F.done) FT_HIP(c, hipEventSynchronize(F.done)); else FT_HIP(c, hipStreamSynchronize(c->stream));
-    const ftk::RenderCounters hrc = *F.h_rc;
+    ftk::RenderCounters hrc{};                                      // the stripes, summed
+    for (int k = 0; k < ftk::kStatStripes; ++k) {
+        const ftk::RenderCounters& s = F.h_tail->stats[k];
+        hrc.rays_shadow += s.rays_shadow; hrc.rays_reflect += s.rays_reflect; hrc.hits_primary += s.hits_primary; hrc.csg_overflow += s.csg_overflow;
+        hrc.ref_equiv += s.ref_equiv; hrc.hits_total += s.hits_total; hrc.tail_in += s.tail_in; hrc.tail_rays += s.tail_rays; hrc.tail_hits += s.tail_hits;
+        hrc.pixels_culled += s.pixels_culled; hrc.rays_shadow_primary += s.rays_shadow_primary; hrc.rays_reflect_primary += s.rays_reflect_primary;
+    }
+    const bool classify_failed = F.h_tail->classify_error != 0;
     const int timing = F.timing; const int32_t spp = F.spp; const int64_t n_pix_total = F.n_pix_total; const bool classify = F.classify;
     hipEvent_t ev0 = F.ev0, ev1 = F.ev1;
-    double k1 = 0.0, k2 = 0.0;
-    for (auto& s : F.spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; if (s.kind == 1) k1 += ms; if (s.kind == 2 || s.kind == 4) k2 += ms; } }
-    if (timing < 2) {                                              // index 0 = everything that was not bracketed (memsets, k_classify, k_blend, statistics)
-        float total = 0; if (ev0 && ev1) (void)hipEventElapsedTime(&total, ev0, ev1);
-        c->k_ms[0] += std::max(0.0, (double)total - k1 - k2);
+    double bracketed = 0.0, traced = 0.0;
+    for (auto& s : F.spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
+        c->k_ms[s.kind] += ms; c->k_launches[s.kind]++; bracketed += ms;
+        if (s.kind == kStageClosest || s.kind == kStageShade || s.kind == kStagePrimary) traced += ms;
     }
+    float total = 0;
+    if (ev0 && ev1) (void)hipEventElapsedTime(&total, ev0, ev1);
+    if (timing < 2) c->k_ms[kStageOther] += std::max(0.0, (double)total - bracketed);   // everything that was not bracketed: the fill, k_classify, k_resolve
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        float ms = 0;
-        if (ev0 && ev1) (void)hipEventElapsedTime(&ms, ev0, ev1);
         stats->rays_primary = F.rays_primary;
         stats->rays_shadow = hrc.rays_shadow; stats->rays_reflect = hrc.rays_reflect;
         // rays the device really traced: primaries of pixel blocks k_classify finished (Colour.Zero for the whole block, no ray generated)
@@ -788,25 +852,31 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
         stats->rays_traced = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, stats->rays_primary_culled) + stats->rays_shadow + stats->rays_reflect;
         stats->rays_reference_equivalent = (double)stats->rays_primary + hrc.ref_equiv;
         stats->hits_primary = hrc.hits_primary; stats->csg_overflow = hrc.csg_overflow;
-        stats->kernel_ms = ms; stats->trace_kernel_ms = k1 + k2;
-        {   // bytes the pipeline has to move by construction (ft_device.h); P primary rays, R reflection rays, H hits, H0 primary hits
-            // rays and hits that k_tail handled never became records: Ti rays were handed to it (written once, read once), Tr spawned and Th shaded inside it
-            const uint64_t Pc = (uint64_t)hrc.pixels_culled * (uint64_t)spp, P = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, Pc), Ti = hrc.tail_in, Tr = hrc.tail_rays, Th = hrc.tail_hits, RR = hrc.rays_reflect, HH = hrc.hits_total;
-            const uint64_t R = RR - std::min(RR, Ti + Tr), Rw = RR - std::min(RR, Tr);
-            const uint64_t H = HH - std::min(HH, Th), H0 = hrc.hits_primary, HL = H - std::min(H, H0);
+        stats->rays_shadow_primary = hrc.rays_shadow_primary; stats->rays_reflect_primary = hrc.rays_reflect_primary;
+        stats->kernel_ms = total; stats->trace_kernel_ms = traced;
+        {   // Bytes the pipeline has to move by construction of its data layout (ft_device.h).  P generated primaries, Rp / R
+            // reflection rays spawned by k_primary / in all, H hits of the staged bounces; k_tail's rays and hits never become records:
+            // Ti rays were handed to it (written once, read once), Tr spawned and Th shaded inside it.
+            const uint64_t P = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, stats->rays_primary_culled);
+            const uint64_t Ti = hrc.tail_in, Tr = hrc.tail_rays, Th = hrc.tail_hits, RR = hrc.rays_reflect, Rp = hrc.rays_reflect_primary;
+            const uint64_t Rstaged = RR - std::min(RR, Ti + Tr);                                  // rays k_closest read (bounce >= 1, not handed to the tail)
+            const uint64_t Hs = hrc.hits_total - std::min(hrc.hits_total, hrc.hits_primary + Th);  // hits k_shade shaded
+            const uint64_t Rs = RR - std::min(RR, Rp + Tr);                                        // rays k_shade spawned
             stats->hits_total = hrc.hits_total;
             stats->rays_tail = Ti + Tr;
-            stats->algorithmic_bytes_closest = P * (ftk::kPixelIdBytes + ftk::kTouchedBytes) + R * 48 + H * (ftk::kHitRecBytes + ftk::kListBytes);
-            stats->algorithmic_bytes_shade = H * (ftk::kHitRecBytes + ftk::kListBytes) + H0 * (2 * ftk::kPixelIdBytes + ftk::kAccBytes) +
-                                             HL * (48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + Rw * ftk::kRayRecBytes;
-            stats->algorithmic_bytes = stats->algorithmic_bytes_closest + stats->algorithmic_bytes_shade +
-                                       Ti * ftk::kRayRecBytes + Th * 2 * ftk::kAccBytes +                       // + k_tail
-                                       P * ftk::kTouchedBytes + H0 * ftk::kAccBytes + 24ull * (uint64_t)n_pix_total +   // + k_blend (and the pixels k_classify wrote)
-                                       (classify ? (uint64_t)n_pix_total * ftk::kPixelIdBytes + (P / (uint64_t)spp) * 2 * ftk::kPixelIdBytes : 0ull);   // + k_classify
+            stats->algorithmic_bytes_primary = P * (ftk::kPixelIdBytes + ftk::kAccBytes) + Rp * ftk::kRayRecBytes;
+            stats->algorithmic_bytes_closest = Rstaged * 48 + Hs * (ftk::kHitRecBytes + ftk::kListBytes);
+            stats->algorithmic_bytes_shade = Hs * (ftk::kHitRecBytes + ftk::kListBytes + 48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + Rs * ftk::kRayRecBytes;
+            const uint64_t out_px = F.format == 1 ? 4 : 24, blocks = (uint64_t)n_pix_total / 64;
+            stats->algorithmic_bytes = stats->algorithmic_bytes_primary + stats->algorithmic_bytes_closest + stats->algorithmic_bytes_shade +
+                                       Ti * ftk::kRayRecBytes + Th * 2 * ftk::kAccBytes +                              // + k_tail
+                                       P * ftk::kAccBytes + out_px * (uint64_t)n_pix_total + 4 * (uint64_t)n_pix_total +  // + k_resolve: samples in, pixels out, pixel ids
+                                       (classify ? blocks * 16 + (P / (uint64_t)spp) * 2 * ftk::kPixelIdBytes : 0ull);    // + k_classify: two ids in, two words out per block; the list
         }
         stats->n_launches = F.n_launches; stats->n_chunks = F.n_chunks;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - F.wall0).count();
     }
+    if (classify_failed) { c->err = "k_classify: a bounded wait ran out (device error)"; return FT_ERR_HIP; }
     if (hrc.csg_overflow) {
         c->err = "CSG hit list overflow on " + std::to_string(hrc.csg_overflow) + " rays: raise csg_mesh_capacity (ft_set_option)";
         return FT_ERR_OVERFLOW;
@@ -824,26 +894,43 @@ static int32_t retire_pending(ft_context* c, ft_stats* stats) {
     return rc;
 }
 
-/* Pipelined rendering (one device): queue the frame and return; see functracer_hip.h. */
+/* Pipelined rendering: queue the frame and return; see functracer_hip.h.  On a context over several devices every device queues
+ * its bands of the frame on its own stream. */
+static int32_t enqueue(ft_context* c, const RenderRequest& q) {
+    if (!c) return FT_ERR_INVALID;
+    return render_frame(c, q, nullptr, nullptr, true);
+}
 int32_t ft_render_enqueue(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                           int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles) {
-    if (!c) return FT_ERR_INVALID;
-    if (!c->peers.empty()) { c->err = "ft_render_enqueue works on a one-device context"; return FT_ERR_UNSUPPORTED; }
-    return render_single(c, cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, nullptr, nullptr, true);
+    return enqueue(c, RenderRequest{cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, 0});
+}
+int32_t ft_render_enqueue_rgba8(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                                int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles) {
+    return enqueue(c, RenderRequest{cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, 1});
 }
 int32_t ft_render_wait(ft_context* c, ft_stats* stats) {
     if (!c) return FT_ERR_INVALID;
     if (c->host_only) return FT_ERR_NO_DEVICE;
     if (stats) std::memset(stats, 0, sizeof *stats);
-    FT_HIP(c, hipSetDevice(c->device));
-    int32_t rc = retire_pending(c, stats);
-    c->accum_open = false;
+    std::vector<ft_context*> devs{c};
+    devs.insert(devs.end(), c->peers.begin(), c->peers.end());
+    int32_t rc = FT_OK;
+    for (ft_context* d : devs) {
+        FT_HIP(c, hipSetDevice(d->device));
+        ft_stats sd;
+        std::memset(&sd, 0, sizeof sd);
+        const int32_t r = retire_pending(d, &sd);
+        d->accum_open = false;
+        if (r != FT_OK && rc == FT_OK) { rc = r; if (d != c) c->err = d->err; }
+        if (stats) { const double wall = std::max(stats->wall_ms, sd.wall_ms); add_stats(stats, sd); stats->wall_ms = wall; }
+    }
     return rc;
 }
 
 int32_t ft_get_kernel_times(ft_context* c, double ms[5], int32_t launches[5]) {
     if (!c || !ms || !launches) return FT_ERR_INVALID;
-    for (int k = 0; k < 5; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
+    for (int k = 0; k < kStages; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
+    for (ft_context* p : c->peers) for (int k = 0; k < kStages; ++k) { ms[k] = std::max(ms[k], p->k_ms[k]); launches[k] = std::max(launches[k], p->k_launches[k]); }   // the slowest device's
     return FT_OK;
 }
 
@@ -866,23 +953,23 @@ static int32_t debug_closest(ft_context* c, const double* origins, const double*
     double* din = c->d_dbg_in.as<double>();
     FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
-    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_fc.p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
     double* dt = c->d_dbg_out.as<double>();
     double* dp = dt + N; double* dn = dp + 3 * N; double* dc = dn + 3 * N;
     int32_t* dh = reinterpret_cast<int32_t*>(dc + 3 * N);
     const size_t lds = lds_bytes_for(c->flat);
     ftk::Launch L{c->stream, c->n_cu * 4, lds, 0};
-    ftk::launch_debug_closest(L, c->dev_scene, din, din + 3 * N, (uint32_t)n, dh, dt, dp, dn, dc, c->d_rc.as<ftk::RenderCounters>());
+    ftk::launch_debug_closest(L, c->dev_scene, din, din + 3 * N, (uint32_t)n, dh, dt, dp, dn, dc, c->d_fc.as<unsigned long long>());
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipMemcpyAsync(t, dt, N * 8, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipMemcpyAsync(p, dp, N * 24, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipMemcpyAsync(nrm, dn, N * 24, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipMemcpyAsync(colour, dc, N * 24, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipMemcpyAsync(hit, dh, N * 4, hipMemcpyDeviceToHost, c->stream));
-    ftk::RenderCounters hrc{};
-    FT_HIP(c, hipMemcpyAsync(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long n_overflow = 0;
+    FT_HIP(c, hipMemcpyAsync(&n_overflow, c->d_fc.p, sizeof n_overflow, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipStreamSynchronize(c->stream));
-    if (hrc.csg_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
+    if (n_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
     return FT_OK;
 }
 
@@ -905,16 +992,71 @@ static int32_t debug_blocked(ft_context* c, const double* origins, const double*
     FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 6 * N, max_dist, N * 8, hipMemcpyHostToDevice, c->stream));
-    FT_HIP(c, hipMemsetAsync(c->d_rc.p, 0, sizeof(ftk::RenderCounters), c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_fc.p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
     const size_t lds = lds_bytes_for(c->flat);
     ftk::Launch L{c->stream, c->n_cu * 4, lds, 0};
-    ftk::launch_debug_blocked(L, c->dev_scene, din, din + 3 * N, din + 6 * N, (uint32_t)n, c->d_dbg_out.as<int32_t>(), c->d_rc.as<ftk::RenderCounters>());
+    ftk::launch_debug_blocked(L, c->dev_scene, din, din + 3 * N, din + 6 * N, (uint32_t)n, c->d_dbg_out.as<int32_t>(), c->d_fc.as<unsigned long long>());
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipMemcpyAsync(blocked, c->d_dbg_out.p, N * 4, hipMemcpyDeviceToHost, c->stream));
-    ftk::RenderCounters hrc{};
-    FT_HIP(c, hipMemcpyAsync(&hrc, c->d_rc.p, sizeof hrc, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long n_overflow = 0;
+    FT_HIP(c, hipMemcpyAsync(&n_overflow, c->d_fc.p, sizeof n_overflow, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipStreamSynchronize(c->stream));
-    if (hrc.csg_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
+    if (n_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
+    return FT_OK;
+}
+
+// getColourForRay (Shading.fs:131-139) for explicit rays through the device path: the rays enter the path kernel (k_tail) as bounce 0
+// with weight 1, so closest hit, shadow queries, shaders and up to max_depth reflection bounces run exactly as they do for a frame's
+// samples.  Streams of soft lights are keyed with seed 0 and sample = ray index.
+static int32_t debug_colour(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t max_depth, double* rgb);
+int32_t ft_debug_colour(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t max_depth, double* rgb) {
+    if (!c) return FT_ERR_INVALID;
+    return with_growing_hit_lists(c, [&] { return debug_colour(c, origins, dirs, n, max_depth, rgb); });
+}
+static int32_t debug_colour(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t max_depth, double* rgb) {
+    if (!c || !origins || !dirs || n < 0 || !rgb || max_depth < 0) return FT_ERR_INVALID;
+    if (max_depth > ftk::kMaxBounce) { c->err = "max_depth above 16"; return FT_ERR_UNSUPPORTED; }
+    if (n >= (1ll << 30)) return FT_ERR_INVALID;
+    if (!need_device(c)) return FT_ERR_NO_DEVICE;
+    if (!c->committed) { c->err = "scene not committed"; return FT_ERR_STATE; }
+    if (n == 0) return FT_OK;
+    FT_HIP(c, hipSetDevice(c->device));
+    int32_t rc;
+    if ((rc = ensure_frame_buffers(c, n, true)) != FT_OK) return rc;
+    const size_t N = (size_t)n, cap = (size_t)c->ray_capacity;
+    std::vector<double> soa(7 * N);
+    std::vector<uint32_t> slot(N);
+    for (size_t i = 0; i < N; ++i) {
+        for (int k = 0; k < 3; ++k) { soa[(size_t)k * N + i] = origins[3 * i + k]; soa[(size_t)(3 + k) * N + i] = dirs[3 * i + k]; }
+        soa[6 * N + i] = 1.0; slot[i] = (uint32_t)i;
+    }
+    auto* fc = c->d_fc.as<ftk::FrameCounters>();
+    FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream));
+    const ftk::RayBuf rb0 = ray_view(c->d_rays[0], c->ray_capacity), rb1 = ray_view(c->d_rays[1], c->ray_capacity);
+    for (int k = 0; k < 7; ++k) FT_HIP(c, hipMemcpyAsync(c->d_rays[0].as<double>() + (size_t)k * cap, soa.data() + (size_t)k * N, N * 8, hipMemcpyHostToDevice, c->stream));
+    FT_HIP(c, hipMemcpyAsync(rb0.slot, slot.data(), N * 4, hipMemcpyHostToDevice, c->stream));
+    const uint32_t n_rays = (uint32_t)n;
+    FT_HIP(c, hipMemcpyAsync(&fc->cc.n_rays[0], &n_rays, 4, hipMemcpyHostToDevice, c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_acc.p, 0, 3 * N * 8, c->stream));
+    const size_t lds = lds_bytes_for(c->flat);
+    int variant = 0;
+    for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;
+    for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;
+    if (!c->flat.meshes.empty()) variant |= 4;
+    ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_tail(lds, variant), lds, variant};
+    ftk::Primary gen{};
+    gen.pixel_ids = nullptr; gen.pix_base = 0; gen.n_pix = n_rays; gen.spp = 1; gen.inv_n_pix = 1.0 / (double)n_rays; gen.seed = 0ull; gen.counts = nullptr; gen.block_map = nullptr;
+    ftk::launch_tail(Lt, c->dev_scene, gen, rb0, rb1, c->d_acc.as<double>(), n_rays, max_depth, n_rays + 1u, fc, 0);
+    FT_HIP(c, hipGetLastError());
+    std::vector<double> planes(3 * N);
+    FT_HIP(c, hipMemcpyAsync(planes.data(), c->d_acc.p, 3 * N * 8, hipMemcpyDeviceToHost, c->stream));
+    FrameTail tail;
+    FT_HIP(c, hipMemcpyAsync(&tail, &fc->stats[0], sizeof tail, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < N; ++i) { rgb[3 * i] = planes[i]; rgb[3 * i + 1] = planes[N + i]; rgb[3 * i + 2] = planes[2 * N + i]; }
+    unsigned long long ovf = 0;
+    for (int k = 0; k < ftk::kStatStripes; ++k) ovf += tail.stats[k].csg_overflow;
+    if (ovf) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
     return FT_OK;
 }
 

@@ -51,7 +51,7 @@ constexpr uint64_t kRayRecBytes = 60, kHitRecBytes = 16;
 // read once; an accumulator 24 B stored (bounce 0) or read-modify-written (later bounces); a pixel 24 B out.
 constexpr uint64_t kPixelIdBytes = 4, kTouchedBytes = 1, kListBytes = 4, kAccBytes = 24;
 
-// Length of the frame's active pixel list (k_classify / k_compact), in device memory: the later stages size themselves from it.
+// Length of the frame's active pixel list (k_classify), in device memory: the later stages size themselves from it.
 struct PixCount { uint32_t n_pix, pad[3]; };
 // Per-chunk device counters (zeroed before every chunk).
 struct ChunkCounters {
@@ -61,13 +61,27 @@ struct ChunkCounters {
     uint32_t work_trace[kMaxBounce + 2][kWorkGroups * 16];
     uint32_t work_shade[kMaxBounce + 2][kWorkGroups * 16];
 };
-// Per-render device statistics (zeroed before every render).
+// Per-render device statistics.  Every wave adds what it counted to one of kStatStripes copies (its wave index mod 64), one
+// no-return atomic per non-zero counter at the end of a launch; the host sums the stripes when it retires the frame.
 struct RenderCounters {
     unsigned long long rays_shadow, rays_reflect, hits_primary, csg_overflow;
     double ref_equiv;
     unsigned long long hits_total;      // hits shaded over all bounces
     unsigned long long tail_in, tail_rays, tail_hits;   // k_tail: rays handed over, reflection rays it spawned, hits it shaded
     unsigned long long pixels_culled;                   // k_classify: pixels whose every primary ray provably misses everything
+    unsigned long long rays_shadow_primary, rays_reflect_primary;   // the k_primary share of rays_shadow / rays_reflect
+    unsigned long long pad[4];                          // 128 bytes: one stripe per pair of cache lines
+};
+constexpr int kStatStripes = 64;
+// Everything a frame's kernels count in, in one allocation so that ONE fill clears it: the chunk counters (cleared again before
+// every further chunk), the statistic stripes, the length of the active pixel list and k_classify's ticket / error words.
+struct FrameCounters {
+    ChunkCounters cc;
+    RenderCounters stats[kStatStripes];
+    PixCount counts;
+    uint32_t classify_ticket;      // k_classify: waves take their 64-block segment in ticket order, so a wave's predecessors are always running
+    uint32_t classify_error;       // set when a bounded wait ran out (never observed; the host then fails the frame instead of hanging)
+    uint32_t pad[2];
 };
 
 struct Camera {                    // ImagePlane (Image.fs:55-63), computed on the host
@@ -95,45 +109,50 @@ struct Primary {
     uint32_t stride;               // ids are y*stride + x: res_h for pixels, res_h + 1 for the corner grid of `samples corner`
     unsigned long long seed;       // keys the counter-based streams of soft shadows / depth of field
     double inv_n_pix, inv_stride;  // 1.0 / n_pix, 1.0 / stride (division-free index arithmetic, see div_by)
-    const PixCount* counts;        // non-null: pixel_ids is the FRAME's active pixel list (k_classify), counts->n_pix its length, and this chunk
-                                   // works on the window [pix_base, pix_base + n_pix) of it
+    const PixCount* counts;        // non-null: the chunk's list is the FRAME's active pixel list (k_classify), counts->n_pix its length, and this
+                                   // chunk works on the window [pix_base, pix_base + n_pix) of it
+    const uint32_t* block_map;     // with counts: block b of the active list is block block_map[b] of pixel_ids; null: pixel_ids is the list itself
 };
-// K2: closest hit of every ray of bounce k; compacts the indices of rays that hit into hit_list.  Bounce 0 also records, one
-// byte per sample, whether the primary ray hit anything (`touched`): untouched samples are Colour.Zero and their accumulator is
-// neither cleared nor read.
-void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, uint32_t tail_threshold,
-                    ChunkCounters* cc, RenderCounters* rc);
-// K3: shading + shadow rays + accumulation for the compacted hits of bounce k; emits bounce k+1 rays.
-// K1: pixel-block classification.  A block of 64 pixels (all its samples) whose ray bundle cannot reach any top-level item is
-// finished on the spot (its output pixels are written as Colour.Zero); the others are compacted into the chunk's active
-// pixel list, which is all the later stages see.
-void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint8_t* block_active, uint32_t* segment_count, uint32_t* active_ids,
-                     uint32_t* active_pos, PixCount* counts, double* out, int whole, double jitter_extent, RenderCounters* rc);
-constexpr uint32_t kClassifySegmentBlocks = 256;               // blocks per compaction segment (ft_kernels.hip: kSegmentBlocks)
+// Bounce 0 fused (k_primary): generate the primary rays of the chunk, closest hit, shadow queries, shaders, reflection spawn, and
+// one colour per sample stored into acc (Colour.Zero for a miss).
+void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint32_t acc_stride, int max_depth, FrameCounters* fc);
+int occupancy_blocks_primary(size_t lds_bytes, int variant);
+// Bounce k >= 1, staged: closest hit of every reflection ray of bounce k; compacts the indices of rays that hit into hit_list.
+void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, uint32_t tail_threshold, FrameCounters* fc);
+// Shading + shadow rays + accumulation for the compacted hits of bounce k >= 1; emits bounce k+1 rays.
+void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
+                  double* acc, uint32_t acc_stride, int bounce, int max_depth, FrameCounters* fc);
 // Tail of the bounce loop (k_tail): once a bounce has fewer than `threshold` rays the per-bounce stages stand down and this one
 // launch follows every remaining path to its end inside registers.
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
-                 int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc);
+                 int max_depth, uint32_t threshold, FrameCounters* fc, int first_bounce = 1);
 int occupancy_blocks_tail(size_t lds_bytes, int variant);
-// Bounce 0 fused (k_primary): generate, closest hit, shadow queries, shaders and reflection spawn for the frame's primary rays.
-void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint8_t* touched, uint32_t acc_stride, int max_depth,
-                    ChunkCounters* cc, RenderCounters* rc);
-int occupancy_blocks_primary(size_t lds_bytes, int variant);
-void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
-                  double* acc, uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc);
-// K4: mean over the spp samples of each pixel, in sample order (Image.fs:112-116).
-// out_index == nullptr: pixel p is written at out_rgb + 3p (packed); else at out_rgb + 3*out_index[p] (in place in the frame).
-void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, uint32_t first, int32_t spp, const uint32_t* out_index, double* out_rgb);
+// Pixel-block classification + compaction in one kernel.  One LANE per 64-pixel block (an 8x8 tile of the pixel list): the block's
+// ray bundle - all samples of its pixels - is bounded by a cone through its outermost jittered corners and tested against every
+// top-level item (bare meshes also against their coarse boxes).  Blocks nothing can be hit from get block_pos = -1 (k_resolve writes
+// their pixels as Colour.Zero; none of their rays is ever generated); the others are appended, in block order, to the frame's active
+// pixel list (pos_block: the block of the pixel list behind each block of the active list), whose length lands in fc->counts.  `epoch` tags this frame's entries of wave_counts.
+struct ClassifyOut { int32_t* block_pos; uint32_t* pos_block; uint32_t* wave_counts; };
+void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, const ClassifyOut& out, double jitter_extent, uint32_t epoch, FrameCounters* fc);
+// The frame's pixels: mean over the spp samples of each pixel of the chunk's window, in sample order (Image.fs:112-116), written as
+// FP64 RGB (out_rgb) and / or as Image.write's RGBA8 bytes (out_rgba, Image.fs:36); with `zero_culled` also Colour.Zero for every
+// pixel of the blocks k_classify finished.  Pixel p of the list goes to out index pixel_ids[p] (whole frame) or p (tiles, packed).
+struct ResolveArgs {
+    const double* acc; uint32_t acc_stride; const PixCount* counts; uint32_t first, n_pix_host; int32_t spp;
+    const uint32_t* pos_block;     // classified frames: block of the ORIGINAL pixel list behind block b of the active list; else null (identity)
+    const int32_t* block_pos;      // non-null: this launch also clears the culled blocks (block_pos[b] < 0) of the n_blocks_total blocks
+    uint32_t n_blocks_total;
+    const uint32_t* pixel_ids;     // the original pixel list (whole frame: out index = pixel id); null: out index = list position
+    double* out_rgb; uint8_t* out_rgba;
+};
+void launch_resolve(const Launch& L, const ResolveArgs& a);
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
-void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb);
-// Sum the per-wave statistic slots 1..n_slots into slot 0.  The caller sizes the slots from the device: n_cu x 8 blocks x 4 waves,
-// the largest grid any launcher here uses (persistent grids are n_cu x clamp_blocks(occupancy) <= 8, the others are clamped to n_cu x 8).
-void launch_reduce_stats(const Launch& L, RenderCounters* slots, uint32_t n_slots);
+void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba);
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,
-                          int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc);
+                          int32_t* hit, double* t, double* p, double* nrm, double* colour, unsigned long long* overflow);
 void launch_debug_blocked(const Launch& L, const DevScene& S, const double* o, const double* d, const double* max_dist,
-                          uint32_t n, int32_t* blocked, RenderCounters* rc);
+                          uint32_t n, int32_t* blocked, unsigned long long* overflow);
 
 } // namespace ftk
 #endif

@@ -1,16 +1,16 @@
 // ft_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the FuncTracer render loop.
 //
-// Pipeline per chunk of samples (DESIGN.md §"Kernels"):
-//   k_classify  which 64-pixel blocks can see anything; the rest are finished on the spot (Colour.Zero)
-//   k_compact   the blocks that can, as the frame's active pixel list (in block order)
-//   (primary rays are generated inside bounce 0 of the two kernels below: Image.fs:83-89, 100-110)
-//   k_closest   closest hit         Scene.fs:112-118 over the flattened Scene.intersect (Scene.fs:67-104)
-//   k_shade     Phong + shadow rays + reflection spawn   Shading.fs:24-139
-//   k_tail      the same two, path by path, for the few rays of the late bounces (one launch instead of two per bounce)
-//   k_blend     per-pixel mean      Image.fs:112-116
-// k_closest / k_shade run once per bounce; reflection rays and hit records live in wavefront buffers in
-// HBM, rays that terminate are dropped by wave-ballot / prefix-sum compaction, so every lane of the next stage
-// is live.  Both are persistent grids whose waves pull 64-ray batches from 64 interleaved cursors.
+// Pipeline (DESIGN.md §"Kernels"); per frame:
+//   k_classify  which 64-pixel blocks can see anything, and the frame's active pixel list (in block order), in one kernel
+// per chunk of samples of the active list:
+//   k_primary   bounce 0, fused: primary rays generated in registers (Image.fs:83-89, 100-110), closest hit (Scene.fs:112-118 over
+//               the flattened Scene.intersect, Scene.fs:67-104), shadow rays + Phong + reflection spawn (Shading.fs:24-139)
+//   k_closest / k_shade   the same two halves as separate stages for the reflection rays of bounce k >= 1: rays and hit records
+//               live in wavefront buffers in HBM, rays that terminate are dropped by wave-ballot / prefix-sum compaction, so every
+//               lane of the next stage is live
+//   k_tail      the same, path by path, for the few rays of the late bounces (one launch instead of two per bounce)
+//   k_resolve   per-pixel mean (Image.fs:112-116), Colour.Zero for the blocks k_classify finished, FP64 and / or RGBA8 (Image.fs:36)
+// All tracing kernels are persistent grids whose waves pull 64-ray batches from 64 interleaved cursors.
 //
 // Execution model notes (wave64, CDNA4):
 //   * one lane = one ray; the scene program, leaf records, matrices, materials, lights and
@@ -667,6 +667,19 @@ struct ItemMask { unsigned long long lo, hi; bool valid; };   // bit k: top-leve
 // A bundle of rays bounded by a cone: apex c (origins within rho of it), unit axis a, half-angle given by cos_t (rounded down) /
 // sin_t (rounded up); par_rows = face directions some ray of the bundle may be nearly parallel to.
 struct Cone { float ax, ay, az, cx, cy, cz, cos_t, sin_t, rho; uint32_t par_rows; };
+// One item (8-float record: centre, radius, face-direction mask, ...) against one cone: false only when no ray inside the cone can
+// give a usable hit on the item.
+FT_DEV bool cone_may_reach(float ix, float iy, float iz, float radius, uint32_t rows, const Cone& B, float origin_mag) {
+    const float vx = ix - B.cx, vy = iy - B.cy, vz = iz - B.cz;
+    const float slack = 1e-5f * (1.0f + origin_mag + fabsf(ix) + fabsf(iy) + fabsf(iz));
+    const float reach = radius * 1.0001f + B.rho + slack;          // sphere radius + origin spread + rounding slack
+    const float h = vx * B.ax + vy * B.ay + vz * B.az;
+    const float w = sqrtf(fmaxf(0.0f, (vx * vx + vy * vy + vz * vz) - h * h));
+    // lower bound of the distance from the centre to the cone: beyond its nearest tangent plane in front of the apex;
+    // behind the apex the cone also lies within the half-space (x - apex).axis >= 0
+    const float beyond = h > 0.0f ? w * B.cos_t - h * B.sin_t : fmaxf(w * B.cos_t, -h);
+    return !(beyond > reach) || (rows & B.par_rows) != 0u;
+}
 // Lane k tests top-level ITEM k: bit k of the result is clear only when no ray inside the cone can give a usable hit on it.
 FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B) {
     ItemMask M{~0ull, ~0ull, true};
@@ -677,16 +690,7 @@ FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B) {
         bool keep = true;
         if (item < S.n_items) {
             const float* I = S.cull_items + 8 * item;
-            const float vx = I[0] - B.cx, vy = I[1] - B.cy, vz = I[2] - B.cz;
-            const uint32_t rows = __float_as_uint(I[4]);
-            const float slack = 1e-5f * (1.0f + origin_mag + fabsf(I[0]) + fabsf(I[1]) + fabsf(I[2]));
-            const float reach = I[3] * 1.0001f + B.rho + slack;     // sphere radius + origin spread + rounding slack
-            const float h = vx * B.ax + vy * B.ay + vz * B.az;
-            const float w = sqrtf(fmaxf(0.0f, (vx * vx + vy * vy + vz * vz) - h * h));
-            // lower bound of the distance from the centre to the cone: beyond its nearest tangent plane in front of the apex;
-            // behind the apex the cone also lies within the half-space (x - apex).axis >= 0
-            const float beyond = h > 0.0f ? w * B.cos_t - h * B.sin_t : fmaxf(w * B.cos_t, -h);
-            keep = !(beyond > reach) || (rows & B.par_rows) != 0u;
+            keep = cone_may_reach(I[0], I[1], I[2], I[3], __float_as_uint(I[4]), B, origin_mag);
         }
         const unsigned long long km = __ballot(keep && item < S.n_items);
         if (pass == 0) M.lo = km; else M.hi = km;
@@ -1040,11 +1044,12 @@ FT_DEV uint32_t batch_lanes_for(uint32_t n, int lane_fold) {
     return b;
 }
 
-// Per-render statistics: every wave of the persistent grid owns one RenderCounters slot (plain read-modify-write,
-// launches on a stream are serialised) and k_reduce_stats sums the slots once per render.  Atomics on shared words
-// at the end of every launch (thousands of waves finishing together) cost about 10 % of the bunny frame.
-FT_DEV RenderCounters* my_stats(RenderCounters* slots) { return slots + 1 + (blockIdx.x * (kBlock / 64) + threadIdx.x / 64); }   // slot 0 = the total
-FT_DEV void wave_add(unsigned long long* dst, unsigned long long v) { if (lane_id() == 0 && v) *dst += v; }
+// Per-render statistics: a wave sums what it counts in registers and adds it, once per launch and per non-zero counter, to one of
+// kStatStripes copies of the counters (no-return atomics, 128 waves per copy at most); the host sums the copies.  Atomics on ONE
+// shared set of words at the end of every launch (thousands of waves finishing together) cost about 10 % of the bunny frame.
+FT_DEV RenderCounters* my_stats(FrameCounters* fc) { return &fc->stats[(blockIdx.x * (kBlock / 64) + threadIdx.x / 64) % (uint32_t)kStatStripes]; }
+FT_DEV void wave_add(unsigned long long* dst, unsigned long long v) { if (lane_id() == 0 && v) atomicAdd(dst, v); }
+FT_DEV void wave_add(double* dst, double v) { if (lane_id() == 0 && v != 0.0) atomicAdd(dst, v); }   // sums of integers below 2^53: exact in any order
 
 // ---------------------------------------------------------------------------------------------
 // Seeded counter-based stream standing in for the reference's unseeded System.Random (Jitter.fs:27, Image.fs:101):
@@ -1097,9 +1102,16 @@ FT_DEV Pix pix_count(PrimaryArg g) {
     return {g->n_pix, g->inv_n_pix};
 }
 
+// Pixel id behind entry `at` of the chunk's list.  In a classified frame the list is the frame's ACTIVE list, kept as a map from
+// its 64-pixel blocks to the blocks of the original pixel list (k_classify): the ids themselves are never copied.
+FT_DEV uint32_t list_pixel(PrimaryArg g, uint32_t at) {
+    const uint32_t* map = g->block_map;
+    return g->pixel_ids[map ? map[at >> 6] * 64u + (at & 63u) : at];
+}
 FT_DEV unsigned long long sample_id(PrimaryArg g, const Pix& px, uint32_t slot) {
     const uint32_t s = div_by(slot, px.inv), pl = slot - s * px.n;
-    return (unsigned long long)g->pixel_ids[g->pix_base + pl] * (unsigned long long)g->spp + s;
+    const uint32_t pid = g->pixel_ids ? list_pixel(g, g->pix_base + pl) : pl;   // no pixel list: the slot is the sample (ft_debug_colour)
+    return (unsigned long long)pid * (unsigned long long)g->spp + s;
 }
 
 // Primary rays are never stored: bounce 0 of k_closest / k_shade regenerates them from the sample index
@@ -1107,7 +1119,7 @@ FT_DEV unsigned long long sample_id(PrimaryArg g, const Pix& px, uint32_t slot) 
 // 64 pixels of one 8x8 block for one jitter offset).
 FT_DEV uint32_t primary_pixel(PrimaryArg g, const Pix& px, uint32_t i) {   // the one memory access a primary ray needs
     const uint32_t s = div_by(i, px.inv), pl = i - s * px.n;
-    return g->pixel_ids[g->pix_base + pl];
+    return list_pixel(g, g->pix_base + pl);
 }
 // `uniform_s`: all 64 lanes of the batch share one jitter offset (n_pix is a multiple of 64): it is then read
 // through a scalar load, which does not queue behind the wave's outstanding vector stores.
@@ -1130,31 +1142,29 @@ FT_DEV Ray primary_ray_from(PrimaryArg g, const Pix& count, uint32_t i, uint32_t
     }
     return r;
 }
-FT_DEV Ray primary_ray(PrimaryArg g, const Pix& px, uint32_t i) { return primary_ray_from(g, px, i, primary_pixel(g, px, i), false); }
 
 struct ClosestArgs {
-    DevScene S; Primary gen; RayBuf rays; HitBuf hits;
-    uint32_t* hit_list; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc; int32_t bounce; uint32_t tail_threshold;
+    DevScene S; RayBuf rays; HitBuf hits;
+    uint32_t* hit_list; FrameCounters* fc; int32_t bounce; uint32_t tail_threshold;
 };
 
 // Resident blocks per CU the compiler must leave room for (measured: 3, 5, 6 are slower - spills or too few waves).
 #ifndef FT_CLOSEST_BLOCKS
 #define FT_CLOSEST_BLOCKS 4
 #endif
+// Closest hit of the reflection rays of bounce k >= 1 (bounce 0 runs in k_primary); the rays that hit are compacted into hit_list.
 template <bool MESH>
 __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST ClosestArgs* K = kernel_args<ClosestArgs>();
     const Scene S = scene_view(K->S);
     const int bounce = K->bounce;
-    ChunkCounters* cc = K->cc;
-    const Pix px = pix_count(&K->gen);                              // once per launch: the count sits two dependent loads away
-    const uint32_t n_pix = px.n;
-    const uint32_t n = bounce == 0 ? n_pix * (uint32_t)K->gen.spp : cc->n_rays[bounce];
-    if (bounce > 0 && n < K->tail_threshold) return;               // few rays left: k_tail follows them to the end (nothing is spawned after this bounce)
+    ChunkCounters* cc = &K->fc->cc;
+    const uint32_t n = cc->n_rays[bounce];
+    if (n < K->tail_threshold) return;                             // few rays left: k_tail follows them to the end (nothing is spawned after this bounce)
     const uint32_t B = batch_lanes_for(n, S.lane_fold);
     const uint32_t n_batches = (n + B - 1) / B;
-    unsigned long long n_hit_wave = 0, n_ovf_wave = 0;
+    unsigned long long n_ovf_wave = 0;
     // Compaction of the rays that hit (wave ballot + prefix sum): hit masks of up to 48 batches are parked in the
     // lanes of three VGPRs (lane k = k-th pending batch) and flushed with ONE reservation on the hit counter.
     uint32_t mask_lo = 0, mask_hi = 0, base_of = 0, pending = 0, pending_hits = 0;
@@ -1163,7 +1173,7 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
             const FT_CONST ClosestArgs* Kf = fresh(K);
             uint32_t* hit_list = Kf->hit_list;
             uint32_t dst = 0;
-            if (lane_id() == 0) dst = atomicAdd(&Kf->cc->n_hits[bounce], pending_hits);
+            if (lane_id() == 0) dst = atomicAdd(&Kf->fc->cc.n_hits[bounce], pending_hits);
             dst = __builtin_amdgcn_readfirstlane(dst);
             for (uint32_t k = 0; k < pending; ++k) {
                 const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_lo, (int)k) |
@@ -1173,41 +1183,25 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
                 dst += (uint32_t)__popcll(m);
             }
         }
-        n_hit_wave += pending_hits;
         pending = 0; pending_hits = 0;
     };
-    // Vector memory operations of a wave complete in issue order, so a load issued after the previous batch's stores
-    // would wait for those stores to be acknowledged: the pixel id of the wave's NEXT batch is requested before the
-    // current one is traced and stored.
-    const bool uniform_s = bounce == 0 && B == 64u && (n_pix & 63u) == 0u;
     BatchCursor cursor(&cc->work_trace[bounce][0]);
     uint32_t bi = cursor.grab(), bi_next = cursor.grab();           // two deep: the index after next is in flight while this batch runs
-    uint32_t pid_next = 0;
-    if (bounce == 0 && bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, px, bi * B + lane_id());
     for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
         const uint32_t base = bi * B;
         const uint32_t i = base + lane_id();
-        const uint32_t pid = pid_next;
         Query<false> q;
         q.active = i < n && lane_id() < B; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
         Ray r{0, 0, 0, 0, 0, 0};
-        {
-            const FT_CONST ClosestArgs* Kb = fresh(K);              // camera, pixel list, ray buffers: loaded here, dead before the trace
-            if (bounce == 0 && bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, px, bi_next * B + lane_id());
-            if (q.active) {
-                if (bounce == 0) r = primary_ray_from(&Kb->gen, px, i, pid, uniform_s);
-                else { const FT_CONST RayBuf& rays = Kb->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; }
-                r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
-            }
+        if (q.active) {
+            const FT_CONST RayBuf& rays = fresh(K)->rays;           // ray buffers: loaded here, dead before the trace
+            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
+            r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
         }
         bool overflow;
-        trace<false, MESH>(S, r, q, lds, overflow, bounce == 0 && K->S.coherent_waves != 0);   // primary rays of one pixel block walk meshes as a packet
+        trace<false, MESH>(S, r, q, lds, overflow, false);
         const bool hit = q.active && q.id0 != ID_MISS;
-        {
-            const FT_CONST ClosestArgs* Ke = fresh(K);
-            if (hit) { const FT_CONST HitBuf& hits = Ke->hits; hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }   // only rays that hit are ever looked at again
-            if (bounce == 0 && q.active) Ke->touched[i] = hit ? 1 : 0;   // samples whose primary ray misses stay Colour.Zero: never stored, never read
-        }
+        if (hit) { const FT_CONST HitBuf& hits = fresh(K)->hits; hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }   // only rays that hit are ever looked at again
         const unsigned long long m = __ballot(hit);
         if (m) {
             if (lane_id() == pending) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); base_of = base; }
@@ -1217,9 +1211,7 @@ __global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestAr
         n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
     }
     flush();
-    RenderCounters* mine = my_stats(fresh(K)->rc);
-    if (bounce == 0) wave_add(&mine->hits_primary, n_hit_wave);
-    wave_add(&mine->csg_overflow, n_ovf_wave);
+    wave_add(&my_stats(fresh(K)->fc)->csg_overflow, n_ovf_wave);
 }
 
 // k_shade variants: FANCY = Oren-Nayar and grid textures compiled in (libm-heavy code: acos, tan, atan2 ...),
@@ -1349,10 +1341,11 @@ FT_DEV void shade_lights(const Scene& S, const Surface& sf, const MaterialV& mat
 
 struct ShadeArgs {
     DevScene S; Primary gen; RayBuf rays; HitBuf hits; RayBuf next;
-    const uint32_t* hit_list; double* acc; ChunkCounters* cc; RenderCounters* rc;
+    const uint32_t* hit_list; double* acc; FrameCounters* fc;
     uint32_t acc_stride; int32_t bounce, max_depth;
 };
 
+// Shading of the compacted hits of bounce k >= 1 (bounce 0 runs in k_primary).
 template <bool FANCY, bool SOFT, bool MESH>
 #ifndef FT_SHADE_BLOCKS
 #define FT_SHADE_BLOCKS 4
@@ -1362,7 +1355,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
     const FT_CONST ShadeArgs* K = kernel_args<ShadeArgs>();
     const Scene S = scene_view(K->S);
     const int bounce = K->bounce;
-    ChunkCounters* cc = K->cc;
+    ChunkCounters* cc = &K->fc->cc;
     const uint32_t n = cc->n_hits[bounce];
     const Pix px = pix_count(&K->gen);                              // once per launch: the count sits two dependent loads away
     const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
@@ -1379,29 +1372,27 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
         bool lit = false;
         unsigned long long sample = 0ull;
         if (active) {
-            const FT_CONST ShadeArgs* Kb = fresh(K);                // buffers and camera: loaded here, dead before the shadow traces
+            const FT_CONST ShadeArgs* Kb = fresh(K);                // buffers: loaded here, dead before the shadow traces
             const uint32_t i = Kb->hit_list[j];
-            Ray r;
-            uint32_t slot;
-            if (bounce == 0) { r = primary_ray(&Kb->gen, px, i); slot = i; }
-            else { const FT_CONST RayBuf& rays = Kb->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; slot = rays.slot[i]; }
+            const FT_CONST RayBuf& rays = Kb->rays;
+            const Ray r{rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
             const FT_CONST HitBuf& hits = Kb->hits;
             // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
             const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
             sf = surface_at<FANCY>(S, ro, hits.t[i], hits.id0[i], hits.id1[i]);
             lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
-            if (SOFT) sample = sample_id(&Kb->gen, px, slot);
+            if (SOFT) sample = sample_id(&Kb->gen, px, rays.slot[i]);
         }
         unsigned long long vis_lo, vis_hi;                         // byte l = occluded shadow samples of light l
-        light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, bounce, bounce == 0 && K->S.coherent_waves != 0, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
+        light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, bounce, false, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
         // ---------------- pass 2: the shaders (Shading.fs:50-107) with everything reloaded ------------------
         Ray r{0, 0, 0, 0, 0, 0};
         double w = 0.0; uint32_t slot = 0;
         const FT_CONST ShadeArgs* K2 = fresh(K);
         if (active) {
             const uint32_t i = K2->hit_list[j];
-            if (bounce == 0) { r = primary_ray(&K2->gen, px, i); w = 1.0; slot = i; }
-            else { const FT_CONST RayBuf& rays = K2->rays; r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i]; }
+            const FT_CONST RayBuf& rays = K2->rays;
+            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i];
         }
         MaterialV mat = material_at(S, sf.material);               // per-lane gather (64 B records, L1/L2 resident)
         if (FANCY) { if (active && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }   // Ray.textureDiffuse (Ray.fs:57-59)
@@ -1409,11 +1400,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
         shade_lights<FANCY, SOFT>(S, sf, mat, r, active, lit, vis_lo, vis_hi, cr, cg, cb);
         if (active) {                                              // one ray per sample per bounce: no write conflicts, fixed order
             double* acc = K2->acc; const uint32_t acc_stride = K2->acc_stride;
-            if (bounce == 0) {                                     // first contribution of the sample: 0 + x = x, so a plain store replaces clear + add
-                acc[slot] = w * cr; acc[(size_t)acc_stride + slot] = w * cg; acc[2 * (size_t)acc_stride + slot] = w * cb;
-            } else {
-                acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
-            }
+            acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
         }
         // reflectionShader (Shading.fs:89-98): every one of the L fragments adds reflectance * colour(reflected ray);
         // those L sub-traces are identical (deterministic lights, or streams keyed without the parent light), so one
@@ -1422,7 +1409,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
         const unsigned long long m = __ballot(spawn);
         const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t dst = 0;
-        if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->cc->n_rays[bounce + 1], cnt);
+        if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->fc->cc.n_rays[bounce + 1], cnt);
         dst = __builtin_amdgcn_readfirstlane(dst);
         if (spawn) {
             const uint32_t o = dst + lanes_below(m);
@@ -1436,17 +1423,17 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
         n_refl_wave += cnt;
         n_hit_wave += (unsigned long long)__popcll(__ballot(active));
     }
-    RenderCounters* mine = my_stats(fresh(K)->rc);
+    RenderCounters* mine = my_stats(fresh(K)->fc);
     wave_add(&mine->rays_shadow, n_shadow_wave);
     wave_add(&mine->rays_reflect, n_refl_wave);
     wave_add(&mine->hits_total, n_hit_wave);
     wave_add(&mine->csg_overflow, n_ovf_wave);
     // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts its shadow rays
     // and each reflective hit L reflection rays (Shading.fs:109-139).
-    if (lane_id() == 0 && (n_hit_wave || n_refl_wave)) {
+    if (n_hit_wave || n_refl_wave) {
         double mult = 1.0;                                          // L^bounce by multiplication: exact, pow is not for L = 3
         for (int k = 0; k < bounce; ++k) mult *= (double)n_lights;
-        mine->ref_equiv += mult * ((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
+        wave_add(&mine->ref_equiv, mult * ((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave));
     }
 }
 
@@ -1461,18 +1448,21 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
 // kernels, so a frame does not depend on which of the two routes bounce 0 takes.
 struct PrimaryArgs {
     DevScene S; Primary gen; RayBuf next;
-    double* acc; uint8_t* touched; ChunkCounters* cc; RenderCounters* rc;
+    double* acc; FrameCounters* fc;
     uint32_t acc_stride; int32_t max_depth;
 };
+// Resident workgroups per CU (measured on the config scenes, profiles/r02_a_fused_vs_split.txt: 2 -> 3 -> 4 is faster at every
+// step although 4 leaves 128 registers per lane and the compiler parks cold state in scratch: the path waits on dependent scalar
+// loads, and a fourth wave per SIMD covers more of that than the spill traffic costs).
 #ifndef FT_PRIMARY_BLOCKS
-#define FT_PRIMARY_BLOCKS 2
+#define FT_PRIMARY_BLOCKS 4
 #endif
 template <bool FANCY, bool SOFT, bool MESH>
 __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_primary(PrimaryArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST PrimaryArgs* K = kernel_args<PrimaryArgs>();
     const Scene S = scene_view(K->S);
-    ChunkCounters* cc = K->cc;
+    ChunkCounters* cc = &K->fc->cc;
     const Pix px = pix_count(&K->gen);
     const uint32_t n_pix = px.n;
     const uint32_t n = n_pix * (uint32_t)K->gen.spp;
@@ -1531,7 +1521,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_prima
             const unsigned long long m = __ballot(spawn);
             const uint32_t cnt = (uint32_t)__popcll(m);
             uint32_t dst = 0;
-            if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->cc->n_rays[1], cnt);
+            if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->fc->cc.n_rays[1], cnt);
             dst = __builtin_amdgcn_readfirstlane(dst);
             if (spawn) {
                 const uint32_t o = dst + lanes_below(m);
@@ -1549,202 +1539,198 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_prima
             const FT_CONST PrimaryArgs* Ka = fresh(K);
             double* acc = Ka->acc; const uint32_t acc_stride = Ka->acc_stride;
             acc[i] = 1.0 * cr; acc[(size_t)acc_stride + i] = 1.0 * cg; acc[2 * (size_t)acc_stride + i] = 1.0 * cb;
-            if (Ka->touched) Ka->touched[i] = 1;
         }
     }
-    RenderCounters* mine = my_stats(fresh(K)->rc);
+    RenderCounters* mine = my_stats(fresh(K)->fc);
     wave_add(&mine->rays_shadow, n_shadow_wave);
+    wave_add(&mine->rays_shadow_primary, n_shadow_wave);
     wave_add(&mine->rays_reflect, n_refl_wave);
+    wave_add(&mine->rays_reflect_primary, n_refl_wave);
     wave_add(&mine->hits_total, n_hit_wave);
     wave_add(&mine->hits_primary, n_hit_wave);
     wave_add(&mine->csg_overflow, n_ovf_wave);
-    if (lane_id() == 0 && (n_hit_wave || n_refl_wave))              // what the F# recursion would trace (Shading.fs:109-139), depth 0
-        mine->ref_equiv += (double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave;
+    // what the F# recursion would trace (Shading.fs:109-139), depth 0
+    wave_add(&mine->ref_equiv, (double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_classify: which 64-pixel blocks of the chunk can see anything at all.  One wave per block: lane = pixel; the cone around
-// the block's primary rays - ALL samples of its pixels: the reference's jitter offsets lie in the unit disc (Jitter.fs:15-21); the
-// pattern is caller-injected here, so the host passes max(1, largest |offset|) and the four rays through the corners
-// (+-extent, +-extent) pixel around each pixel centre bound them - is tested against the bounding
-// sphere of every top-level item (items_in_cone, conservative).  A block no item can be hit from is finished here: its
-// pixels are written as Colour.Zero (Scene.fs:116, no hit) and none of its W*H*spp rays is generated.  The other blocks are
-// appended to the chunk's active pixel list, in blocks of 64 so a wavefront stays one compact bundle.  The host only runs
-// this for pinhole cameras over whole 64-pixel blocks and scenes made of bounded items.
+// k_classify: which 64-pixel blocks of the frame can see anything at all, and the list of those that can.  One LANE per block (an
+// 8x8 tile of the pixel list), one workgroup per 256 consecutive blocks.  The rays of a block - ALL samples of its pixels: the caller's
+// jitter offsets lie within +-extent pixels (the reference's in the unit disc, Jitter.fs:15-21) - have directions k + jx i + jy j
+// with (jx, jy) in a rectangle; their angle to any axis inside that pyramid is largest at one of its four corners, so the cone
+// around the centre ray through the four outermost corners bounds them all.  The cone is tested against the bounding sphere of
+// every top-level item (cone_may_reach, conservative: explicit slack, items with a face direction some ray of the block may be
+// parallel to are kept, Plane.fs:13-16), a bare mesh that survives also against the <= 64 boxes holding its triangles.  A block
+// nothing can be hit from is finished: block_pos = -1, k_resolve writes its pixels as Colour.Zero (Scene.fs:116) and none of its
+// 64 x spp rays is ever generated.  The other blocks are appended to the frame's active pixel list IN BLOCK ORDER (neighbouring
+// blocks stay neighbours; later stages batch by list position; the list is a map from its blocks to those of the pixel list, no
+// pixel id is copied: a wave copying the ids of 64 kept blocks one after the other took 35 us) without a second kernel: workgroups take their 256-block segment in
+// ticket order, publish how many blocks they keep, and add up the counts of the tickets before theirs (all of them already running, so
+// the wait is bounded by the slowest classification; it is also bounded by a poll limit that fails the frame rather than hang).
+// The host only runs this for pinhole cameras, pixel lists made of 8x8 tiles and scenes made of bounded items.
 struct ClassifyArgs {
-    DevScene S; Primary gen;                                        // gen.pixel_ids / pix_base / n_pix: the chunk's full pixel list
-    uint8_t* block_active; uint32_t* segment_count; double* out; RenderCounters* rc; int32_t whole;
-    double jitter_extent;                                           // max(1, largest |offset| of the caller's jitter pattern): half-width, in pixels, of the square all samples of a pixel lie in
+    DevScene S; Primary gen;                                        // gen.pixel_ids / n_pix: the frame's full pixel list (8x8 tiles)
+    ClassifyOut out; FrameCounters* fc;
+    double jitter_extent;                                           // max(1, largest |offset| of the caller's jitter pattern), in pixels
+    uint32_t epoch;                                                 // tags this frame's entries of out.wave_counts (never cleared)
 };
-constexpr uint32_t kSegmentBlocks = 256;                            // blocks per compaction segment (one k_compact workgroup)
-constexpr uint32_t kClassifyRun = 4;                                // consecutive blocks per wave: one list reservation for all of them
+constexpr uint32_t kClassifyPollLimit = 1u << 22;
 
-__global__ __launch_bounds__(kBlock) void k_classify(ClassifyArgs) {
+constexpr uint32_t kClassifyBlock = 256;                            // threads = pixel blocks per workgroup
+__global__ __launch_bounds__(kClassifyBlock) void k_classify(ClassifyArgs) {
+    __shared__ uint32_t sh_ticket, sh_before, sh_wave_keep[kClassifyBlock / 64];
     const FT_CONST ClassifyArgs* K = kernel_args<ClassifyArgs>();
     const Scene S = scene_view(K->S);
     const PrimaryArg g = &K->gen;
     const uint32_t n_blocks = g->n_pix / 64u;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64, n_waves = gridDim.x * (kBlock / 64);
-    unsigned long long culled = 0ull;
-    for (uint32_t run = wave * kClassifyRun; run < n_blocks; run += n_waves * kClassifyRun) {
-        uint32_t keep_mask = 0u;                                    // bit j: block run + j is active
-        uint32_t pid_of[kClassifyRun];
+    if (threadIdx.x == 0) sh_ticket = atomicAdd(&K->fc->classify_ticket, 1u);
+    __syncthreads();
+    const uint32_t ticket = sh_ticket, wave = threadIdx.x / 64u;
+    const uint32_t blk = ticket * kClassifyBlock + threadIdx.x;
+    const bool valid = blk < n_blocks;
+    // Every lane runs the whole classification (lanes past the end of the list redo the last block): the box test below hands
+    // lane b the role of BOX b, so no lane may sit out.
+    const uint32_t lb = valid ? blk : n_blocks - 1u;
+    // the tile's first and last pixel are its top-left and bottom-right corners
+    const uint32_t pid0 = g->pixel_ids[(size_t)lb * 64u], pid1 = g->pixel_ids[(size_t)lb * 64u + 63u];
+    const uint32_t y0 = div_by(pid0, g->inv_stride), x0 = pid0 - y0 * g->stride, y1 = div_by(pid1, g->inv_stride), x1 = pid1 - y1 * g->stride;
+    const double ext = K->jitter_extent * 1.000001;
+    const double jxa = g->cam.tlx + ((double)x0 - ext) * g->cam.pw, jxb = g->cam.tlx + ((double)x1 + ext) * g->cam.pw;
+    const double jya = g->cam.tly - ((double)y1 + ext) * g->cam.ph, jyb = g->cam.tly - ((double)y0 - ext) * g->cam.ph;
+    double d[5][3];                                                 // centre, then the corners in order around the block
 #pragma unroll
-        for (uint32_t j = 0; j < kClassifyRun; ++j) {
-            const uint32_t blk = run + j;
-            pid_of[j] = 0u;
-            if (blk >= n_blocks) continue;                          // wave-uniform
-            const uint32_t pid = g->pixel_ids[g->pix_base + blk * 64u + lane_id()];
-            pid_of[j] = pid;
-            const uint32_t py = div_by(pid, g->inv_stride), px = pid - py * g->stride;
-            const double cxp = g->cam.tlx + (double)px * g->cam.pw, cyp = g->cam.tly - (double)py * g->cam.ph;
-            float cos_dev = 1.0f, ax = 0.f, ay = 0.f, az = 0.f;
-            double dlo[3], dhi[3];                                  // per-lane range of the ray direction over the pixel's jitter square
-            bool finite = true;
+    for (int c = 0; c < 5; ++c) {
+        const double jx = c == 0 ? 0.5 * (jxa + jxb) : ((c == 1 || c == 4) ? jxa : jxb), jy = c == 0 ? 0.5 * (jya + jyb) : (c <= 2 ? jya : jyb);
+        d[c][0] = (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0]; d[c][1] = (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1];
+        d[c][2] = (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2];
+    }
+    float ax = 0.f, ay = 0.f, az = 0.f, cos_dev = 1.0f;
+    bool finite = true;
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {                           // centre, then the four corners
-                const double ext = K->jitter_extent * 1.000001;
-                const double ox = c == 0 ? 0.0 : ((c & 1) ? ext : -ext), oy = c == 0 ? 0.0 : ((c & 2) ? ext : -ext);
-                const double jx = cxp + ox * g->cam.pw, jy = cyp + oy * g->cam.ph;
-                const double dx = (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0], dy = (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1],
-                             dz = (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2];
-                float fx = (float)dx, fy = (float)dy, fz = (float)dz;
-                const float l2 = fx * fx + fy * fy + fz * fz;
-                finite = finite && l2 > 1e-30f && l2 < 1e30f;
-                const float inv = __builtin_amdgcn_rsqf(l2);
-                fx *= inv; fy *= inv; fz *= inv;
-                if (c == 0) {                                       // axis: the centre ray of the block's first pixel
-                    ax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fx))); ay = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fy)));
-                    az = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fz)));
-                    dlo[0] = dhi[0] = dx; dlo[1] = dhi[1] = dy; dlo[2] = dhi[2] = dz;
-                } else {
-                    cos_dev = fminf(cos_dev, ax * fx + ay * fy + az * fz);
-                    dlo[0] = fmin(dlo[0], dx); dhi[0] = fmax(dhi[0], dx); dlo[1] = fmin(dlo[1], dy); dhi[1] = fmax(dhi[1], dy); dlo[2] = fmin(dlo[2], dz); dhi[2] = fmax(dhi[2], dz);
-                }
+    for (int c = 0; c < 5; ++c) {
+        float fx = (float)d[c][0], fy = (float)d[c][1], fz = (float)d[c][2];
+        const float l2 = fx * fx + fy * fy + fz * fz;
+        finite = finite && l2 > 1e-30f && l2 < 1e30f;
+        const float inv = __builtin_amdgcn_rsqf(l2);
+        fx *= inv; fy *= inv; fz *= inv;
+        if (c == 0) { ax = fx; ay = fy; az = fz; } else cos_dev = fminf(cos_dev, ax * fx + ay * fy + az * fz);
+    }
+    const float cos_t = cos_dev - 1e-5f;                            // cos of the half-angle, made smaller (cone wider)
+    const bool bounded = finite && cos_t > 0.3f;                    // a wide or degenerate bundle bounds nothing: the block stays
+    // face directions some ray of the block may be nearly parallel to (Plane.fs:13-16): row . d is affine in (jx, jy), so over the
+    // block's rectangle it lies between its values at the four corners
+    uint32_t par_rows = 0;
+    for (int k = 0; k < S.n_cull_rows; ++k) {
+        cdp Rw = S.cull_rows + 3u * (uint32_t)k;
+        double lo = __builtin_inf(), hi = -__builtin_inf();
+#pragma unroll
+        for (int c = 1; c < 5; ++c) { const double v = dot3(Rw[0], Rw[1], Rw[2], d[c][0], d[c][1], d[c][2]); lo = fmin(lo, v); hi = fmax(hi, v); }
+        if (lo < 2.000001 * kEps && hi > -2.000001 * kEps) par_rows |= 1u << k;
+    }
+    const float cox = (float)g->cam.o[0], coy = (float)g->cam.o[1], coz = (float)g->cam.o[2];
+    const float origin_mag = fabsf(cox) + fabsf(coy) + fabsf(coz);
+    const Cone B{ax, ay, az, cox, coy, coz, cos_t, sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f, 1e-5f * (1.0f + origin_mag), par_rows};
+    bool keep = !bounded;
+    for (int item = 0; item < S.n_items; ++item) {                  // wave-uniform: the item record comes through scalar loads
+        if (!__any(!keep)) break;
+        const FT_CONST float* I = to_const_as(S.cull_items) + 8u * (uint32_t)item;
+        bool reach = !keep && cone_may_reach(I[0], I[1], I[2], I[3], __float_as_uint(I[4]), B, origin_mag);
+        const uint32_t n_box = __float_as_uint(I[6]);
+        if (n_box != 0u && __any(reach)) {
+            // A bare mesh that survived its bounding sphere: the pyramid through the block's corners, taken into the mesh's model space,
+            // must reach one of its coarse boxes (a box wholly behind one side plane of the pyramid is out of reach).  Roles swap for
+            // this test: the blocks that need it take turns, their four side planes are broadcast, and lane b tests BOX b - all boxes
+            // of the mesh at once instead of one scalar-load round trip per box and block.
+            const uint32_t first_box = __float_as_uint(I[5]), leaf = __float_as_uint(I[7]);
+            const LeafHead Hm = leaf_head(S, leaf);
+            cdp Mw = S.leaves + 16ull * leaf;
+            Ray corner[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) to_model(Mw, (Hm.flags & LF_XFORM) != 0, Ray{g->cam.o[0], g->cam.o[1], g->cam.o[2], d[c + 1][0], d[c + 1][1], d[c + 1][2]}, corner[c]);
+            float pn[4][3]; uint32_t sided = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                           // side plane through corner rays c and c+1, oriented by the opposite corner
+                const Ray& a = corner[c]; const Ray& bq = corner[(c + 1) & 3]; const Ray& opp = corner[(c + 2) & 3];
+                float nx = (float)(a.dy * bq.dz - a.dz * bq.dy), ny = (float)(a.dz * bq.dx - a.dx * bq.dz), nz = (float)(a.dx * bq.dy - a.dy * bq.dx);
+                const float side = nx * (float)opp.dx + ny * (float)opp.dy + nz * (float)opp.dz;
+                if (side < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+                pn[c][0] = nx; pn[c][1] = ny; pn[c][2] = nz; if (side != 0.0f) sided |= 1u << c;
             }
-            bool active = true;
-            const float cos_t = wave_min(cos_dev) - 1e-5f;
-            if (!__any(!finite) && cos_t > 0.3f) {
-                // face directions some ray of the block may be nearly parallel to (Plane.fs:13-16): d is affine in the jitter, so
-                // row . d over the pixel's square lies between the sums of the per-component extremes
-                uint32_t par_rows = 0;
-                for (int k = 0; k < S.n_cull_rows; ++k) {
-                    cdp Rw = S.cull_rows + 3u * (uint32_t)k;
-                    double lo = 0.0, hi = 0.0;
+            const float ox = (float)corner[0].ox, oy = (float)corner[0].oy, oz = (float)corner[0].oz;   // the camera in model space: the same for every block
+            bool found = false;
+            for (uint32_t b0 = 0; b0 < n_box; b0 += 64u) {          // all 64 lanes are executing here (no enclosing per-lane branch)
+                const bool has_box = b0 + lane_id() < n_box;
+                float bx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (has_box) { const float* Bx = S.coarse_boxes + 6u * (first_box + b0 + lane_id()); for (int k = 0; k < 6; ++k) bx[k] = Bx[k]; }
+                unsigned long long todo = __ballot(reach && !found);
+                while (todo) {                                       // wave-uniform: one block at a time against (up to) 64 boxes
+                    const int src = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
+                    const uint32_t sd = (uint32_t)__builtin_amdgcn_readlane((int)sided, src);
+                    bool in = has_box;
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) { const double u = Rw[a] * dlo[a], v = Rw[a] * dhi[a]; lo += fmin(u, v); hi += fmax(u, v); }
-                    if (__any(lo < 2.000001 * kEps && hi > -2.000001 * kEps)) par_rows |= 1u << k;
-                }
-                const Cone B{ax, ay, az, (float)g->cam.o[0], (float)g->cam.o[1], (float)g->cam.o[2], cos_t, sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f,
-                             1e-5f * (1.0f + fabsf((float)g->cam.o[0]) + fabsf((float)g->cam.o[1]) + fabsf((float)g->cam.o[2])), par_rows};
-                ItemMask M = items_in_cone(S, B);
-                // A bare mesh that survived its bounding sphere is tested once more, against the <= 64 boxes that hold all its
-                // triangles: the pyramid through the block's outermost pixel corners, taken into the mesh's model space, must reach
-                // one of them (lane k: box k; a box wholly behind one side plane of the pyramid is out of reach).
-                for (int half = 0; half < 2; ++half) {
-                    unsigned long long todo = half == 0 ? M.lo : M.hi;
-                    while (todo) {
-                        const int bit = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
-                        const uint32_t item = (uint32_t)(64 * half + bit);
-                        const FT_CONST float* I = to_const_as(S.cull_items) + 8u * item;
-                        const uint32_t n_box = __float_as_uint(I[6]);
-                        if (n_box == 0u) continue;
-                        const uint32_t first_box = __float_as_uint(I[5]), leaf = __float_as_uint(I[7]);
-                        // pixel bounds of the block (+- one pixel of jitter), as image-plane coordinates
-                        const float fpx = (float)px, fpy = (float)py;
-                        const float x0 = wave_min(fpx), x1 = -wave_min(-fpx), y0 = wave_min(fpy), y1 = -wave_min(-fpy);
-                        const double reach_px = K->jitter_extent + 0.001;
-                        const double jx0 = g->cam.tlx + ((double)x0 - reach_px) * g->cam.pw, jx1 = g->cam.tlx + ((double)x1 + reach_px) * g->cam.pw;
-                        const double jy0 = g->cam.tly - ((double)y1 + reach_px) * g->cam.ph, jy1 = g->cam.tly - ((double)y0 - reach_px) * g->cam.ph;
-                        const LeafHead Hm = leaf_head(S, leaf);
-                        cdp Mw = S.leaves + 16ull * leaf;
-                        Ray corner[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {                   // corners in order around the block
-                            const double jx = (c == 0 || c == 3) ? jx0 : jx1, jy = (c < 2) ? jy0 : jy1;
-                            const Ray w{g->cam.o[0], g->cam.o[1], g->cam.o[2], (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0],
-                                        (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1], (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2]};
-                            to_model(Mw, (Hm.flags & LF_XFORM) != 0, w, corner[c]);
-                        }
-                        const float ox = (float)corner[0].ox, oy = (float)corner[0].oy, oz = (float)corner[0].oz;
-                        bool reach = false;
-                        for (uint32_t b0 = 0; b0 < n_box; b0 += 64u) {
-                            const uint32_t bx = b0 + lane_id();
-                            bool in = bx < n_box;
-                            if (in) {
-                                const float* Bx = S.coarse_boxes + 6u * (first_box + bx);
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {           // side plane through corner rays c and c+1, oriented by the opposite corner
-                                    const Ray& a = corner[c]; const Ray& bq = corner[(c + 1) & 3]; const Ray& opp = corner[(c + 2) & 3];
-                                    float nx = (float)(a.dy * bq.dz - a.dz * bq.dy), ny = (float)(a.dz * bq.dx - a.dx * bq.dz), nz = (float)(a.dx * bq.dy - a.dy * bq.dx);
-                                    const float side = nx * (float)opp.dx + ny * (float)opp.dy + nz * (float)opp.dz;
-                                    if (side < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
-                                    // the box corner furthest along the inward normal
-                                    const float qx = (nx > 0.0f ? Bx[3] : Bx[0]) - ox, qy = (ny > 0.0f ? Bx[4] : Bx[1]) - oy, qz = (nz > 0.0f ? Bx[5] : Bx[2]) - oz;
-                                    const float d = nx * qx + ny * qy + nz * qz;
-                                    const float slack = 1e-4f * (fabsf(nx * qx) + fabsf(ny * qy) + fabsf(nz * qz));
-                                    if (d < -slack && side != 0.0f) in = false;     // wholly outside this side of the pyramid
-                                }
-                            }
-                            if (__any(in)) { reach = true; break; }
-                        }
-                        if (!reach) { if (half == 0) M.lo &= ~(1ull << bit); else M.hi &= ~(1ull << bit); }
+                    for (int c = 0; c < 4; ++c) {
+                        const float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn[c][0]), src)), ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn[c][1]), src)),
+                                    nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn[c][2]), src));
+                        // the box corner furthest along the inward normal
+                        const float qx = (nx > 0.0f ? bx[3] : bx[0]) - ox, qy = (ny > 0.0f ? bx[4] : bx[1]) - oy, qz = (nz > 0.0f ? bx[5] : bx[2]) - oz;
+                        const float dd = nx * qx + ny * qy + nz * qz;
+                        const float slack = 1e-4f * (fabsf(nx * qx) + fabsf(ny * qy) + fabsf(nz * qz));
+                        if (dd < -slack && ((sd >> c) & 1u)) in = false;    // wholly outside this side of the pyramid
                     }
+                    const bool any_in = __any(in);
+                    if ((int)lane_id() == src) found = any_in;
                 }
-                active = (M.lo | M.hi) != 0ull || S.n_items > 128;
             }
-            if (active) keep_mask |= 1u << j;
-            else {                                                  // finished: Colour.Zero for every pixel of the block
-                culled += 64ull;
-                const size_t o = K->whole ? (size_t)pid : (size_t)(blk * 64u + lane_id());
-                double* out = K->out;
-                out[3 * o] = 0.0; out[3 * o + 1] = 0.0; out[3 * o + 2] = 0.0;
-            }
+            reach = reach && found;
         }
-        // Verdicts go to a byte per block and a count per segment of 256 blocks; k_compact turns them into the active list IN BLOCK
-        // ORDER (an atomic cursor here would scatter neighbouring blocks over the list, and later stages batch by list position).
-        if (lane_id() < kClassifyRun && run + lane_id() < n_blocks) K->block_active[run + lane_id()] = (uint8_t)((keep_mask >> lane_id()) & 1u);
-        const uint32_t n_keep = (uint32_t)__popc(keep_mask);
-        if (n_keep && lane_id() == 0) atomicAdd(&K->segment_count[run / kSegmentBlocks], n_keep);     // a run never straddles a segment
+        keep = keep || reach;
     }
-    wave_add(&my_stats(K->rc)->pixels_culled, culled);
-}
-
-// k_compact: the active pixel list, in block order.  Workgroup s owns segment s (256 blocks): its first list position is the
-// sum of the counts of the segments before it, the rank of a block inside the segment comes from the flags, and each wave
-// then copies the 64 pixel ids of its blocks (coalesced).  The last segment publishes the length of the list.
-struct CompactArgs {
-    const uint32_t* pixel_ids; const uint8_t* block_active; const uint32_t* segment_count;
-    uint32_t* active_ids; uint32_t* active_pos; PixCount* counts; uint32_t n_blocks, n_segments;
-};
-__global__ __launch_bounds__(kBlock) void k_compact(CompactArgs a) {
-    __shared__ uint32_t partial[kBlock / 64];
-    __shared__ uint32_t dst_of[kSegmentBlocks];
-    const uint32_t seg = blockIdx.x, t = threadIdx.x, wave = t / 64;
-    uint32_t before = 0;
-    for (uint32_t j = t; j < seg; j += kBlock) before += a.segment_count[j];
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
-    if (lane_id() == 0) partial[wave] = before;
+    keep = keep && valid;
+    // ---- compaction in block order
+    const FT_CONST ClassifyOut& out = K->out;
+    const unsigned long long km = __ballot(keep);
+    const uint32_t n_keep = (uint32_t)__popcll(km);
+    if (lane_id() == 0) sh_wave_keep[wave] = n_keep;
     __syncthreads();
-    const uint32_t base = partial[0] + partial[1] + partial[2] + partial[3];
-    __syncthreads();
-    const uint32_t blk = seg * kSegmentBlocks + t;
-    const bool on = blk < a.n_blocks && a.block_active[blk] != 0;
-    const unsigned long long m = __ballot(on);
-    if (lane_id() == 0) partial[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t rank = lanes_below(m);
-    for (uint32_t w = 0; w < wave; ++w) rank += partial[w];
-    dst_of[t] = on ? base + rank : 0xFFFFFFFFu;
-    __syncthreads();
-    for (uint32_t k = wave; k < kSegmentBlocks; k += kBlock / 64) {
-        const uint32_t d = dst_of[k];
-        if (d == 0xFFFFFFFFu) continue;
-        const uint32_t src = (seg * kSegmentBlocks + k) * 64u + lane_id();
-        a.active_ids[d * 64u + lane_id()] = a.pixel_ids[src];
-        a.active_pos[d * 64u + lane_id()] = src;
+    uint32_t n_keep_wg = 0, before_wave = 0;
+    for (uint32_t w = 0; w < kClassifyBlock / 64; ++w) { if (w < wave) before_wave += sh_wave_keep[w]; n_keep_wg += sh_wave_keep[w]; }
+    const uint32_t epoch = K->epoch;
+    // Only the word itself travels between workgroups (no data is published behind it), so relaxed device-scope atomics are enough: an
+    // acquire in the poll loop would invalidate the XCD's L2 on every poll, for every wave on it (measured: 238 us instead of 45).
+    // One workgroup per 256 blocks keeps the words few: every reader loads all the words before its own, and a device-scope line
+    // serves a few hundred loads per microsecond (one WAVE per 64 blocks: 128 K loads on 16 lines, 35 us of a 45 us kernel).
+    if (threadIdx.x == 0) __hip_atomic_store(&out.wave_counts[ticket], (epoch << 10) | (n_keep_wg + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+        uint32_t before = 0;
+        bool timed_out = false;
+        for (uint32_t j0 = 0; j0 < ticket; j0 += 64u) {             // kept blocks of every earlier ticket (they are all running: tickets are taken at workgroup start)
+            const uint32_t j = j0 + lane_id();
+            uint32_t v = (epoch << 10) | 1u;
+            if (j < ticket) {
+                uint32_t polls = 0;
+                for (;;) {
+                    v = __hip_atomic_load(&out.wave_counts[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 10) == epoch || ++polls > kClassifyPollLimit) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if ((v >> 10) != epoch) { timed_out = true; v = (epoch << 10) | 1u; }
+            }
+            uint32_t c = (v & 0x3FFu) - 1u;
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+            before += c;
+        }
+        if (__any(timed_out) && lane_id() == 0) atomicOr(&K->fc->classify_error, 1u);
+        if (lane_id() == 0) sh_before = before;
     }
-    if (seg + 1 == a.n_segments && t == 0) a.counts->n_pix = 64u * (base + partial[0] + partial[1] + partial[2] + partial[3]);
+    __syncthreads();
+    const uint32_t before = sh_before + before_wave;                // kept blocks before this wave's first
+    const uint32_t pos = before + lanes_below(km);
+    if (valid) out.block_pos[blk] = keep ? (int32_t)pos : -1;
+    if (keep) out.pos_block[pos] = blk;                             // the active list as a block map: pixel ids stay where they are
+    if (threadIdx.x == 0 && (ticket + 1u) * kClassifyBlock >= n_blocks && ticket * kClassifyBlock < n_blocks)
+        K->fc->counts.n_pix = 64u * (sh_before + n_keep_wg);        // the last segment publishes the length of the list
+    const unsigned long long n_valid = (unsigned long long)__popcll(__ballot(valid));
+    wave_add(&K->fc->stats[(ticket * (kClassifyBlock / 64) + wave) % (uint32_t)kStatStripes].pixels_culled, 64ull * (n_valid - (unsigned long long)n_keep));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1756,8 +1742,9 @@ __global__ __launch_bounds__(kBlock) void k_compact(CompactArgs a) {
 // accumulation order per sample as the staged bounces, so frames do not depend on where the hand-over happens.
 struct TailArgs {
     DevScene S; Primary gen; RayBuf rays[2];
-    double* acc; ChunkCounters* cc; RenderCounters* rc;
+    double* acc; FrameCounters* fc;
     uint32_t acc_stride; int32_t max_depth; uint32_t threshold;
+    int32_t first_bounce;                                          // 1 in a frame; 0 for ft_debug_colour, whose rays are primary rays (rays[0], n_rays[0])
 };
 
 #ifndef FT_TAIL_BLOCKS
@@ -1767,11 +1754,11 @@ template <bool FANCY, bool SOFT, bool MESH>
 __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(TailArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST TailArgs* K = kernel_args<TailArgs>();
-    ChunkCounters* cc = K->cc;
+    ChunkCounters* cc = &K->fc->cc;
     const int max_depth = K->max_depth;
-    int k0 = 0; uint32_t n = 0;
-    for (int k = 1; k <= max_depth; ++k) { const uint32_t nk = cc->n_rays[k]; if (nk > 0u && nk < K->threshold) { k0 = k; n = nk; break; } }
-    if (k0 == 0) return;
+    int k0 = -1; uint32_t n = 0;
+    for (int k = K->first_bounce; k <= max_depth; ++k) { const uint32_t nk = cc->n_rays[k]; if (nk > 0u && nk < K->threshold) { k0 = k; n = nk; break; } }
+    if (k0 < 0) return;
     const Pix px = pix_count(&K->gen);
     const Scene S = scene_view(K->S);
     const int n_lights = S.n_lights;
@@ -1835,7 +1822,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(Tai
             alive = spawn;
         }
     }
-    RenderCounters* mine = my_stats(fresh(K)->rc);
+    RenderCounters* mine = my_stats(fresh(K)->fc);
     wave_add(&mine->rays_shadow, n_shadow_wave);
     wave_add(&mine->rays_reflect, n_refl_wave);
     wave_add(&mine->hits_total, n_hit_wave);
@@ -1843,65 +1830,62 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(Tai
     wave_add(&mine->tail_in, n_in_wave);
     wave_add(&mine->tail_rays, n_refl_wave);
     wave_add(&mine->tail_hits, n_hit_wave);
-    if (lane_id() == 0 && ref_wave != 0.0) mine->ref_equiv += ref_wave;
+    wave_add(&mine->ref_equiv, ref_wave);
 }
 
-__global__ __launch_bounds__(64) void k_reduce_stats(RenderCounters* slots, uint32_t n_slots) {   // one wave per 64 slots; slot 0 receives the totals
-    const uint32_t k = 1 + blockIdx.x * 64 + threadIdx.x;
-    RenderCounters s{0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0};
-    if (k <= n_slots) s = slots[k];
-    for (int off = 32; off > 0; off >>= 1) {                       // wave reduction, then one lane adds to the total
-        s.rays_shadow += __shfl_down(s.rays_shadow, off); s.rays_reflect += __shfl_down(s.rays_reflect, off); s.hits_primary += __shfl_down(s.hits_primary, off);
-        s.csg_overflow += __shfl_down(s.csg_overflow, off); s.ref_equiv += __shfl_down(s.ref_equiv, off); s.hits_total += __shfl_down(s.hits_total, off);
-        s.tail_in += __shfl_down(s.tail_in, off); s.tail_rays += __shfl_down(s.tail_rays, off); s.tail_hits += __shfl_down(s.tail_hits, off);
-        s.pixels_culled += __shfl_down(s.pixels_culled, off);
-    }
-    if (threadIdx.x == 0) {
-        RenderCounters* t = slots;
-        if (s.rays_shadow) atomicAdd(&t->rays_shadow, s.rays_shadow);
-        if (s.rays_reflect) atomicAdd(&t->rays_reflect, s.rays_reflect);
-        if (s.hits_primary) atomicAdd(&t->hits_primary, s.hits_primary);
-        if (s.csg_overflow) atomicAdd(&t->csg_overflow, s.csg_overflow);
-        if (s.ref_equiv != 0.0) atomicAdd(&t->ref_equiv, s.ref_equiv);
-        if (s.hits_total) atomicAdd(&t->hits_total, s.hits_total);
-        if (s.tail_in) atomicAdd(&t->tail_in, s.tail_in);
-        if (s.tail_rays) atomicAdd(&t->tail_rays, s.tail_rays);
-        if (s.tail_hits) atomicAdd(&t->tail_hits, s.tail_hits);
-        if (s.pixels_culled) atomicAdd(&t->pixels_culled, s.pixels_culled);
-    }
+// Image.write's toByte (Image.fs:36; Math.clamp, Math.fs:12-16): clamp to [0, 1] (NaN passes the clamp), * 255, truncate.
+FT_DEV uint32_t to_byte(double x) {
+    if (x > 1.0) x = 1.0; else if (x < 0.0) x = 0.0;
+    x = x * 255.0;
+    return (x != x) ? 0u : (uint32_t)(uint8_t)x;
+}
+FT_DEV void write_pixel(double* out_rgb, uint8_t* out_rgba, size_t o, double r, double g, double b) {
+    if (out_rgb) { out_rgb[3 * o] = r; out_rgb[3 * o + 1] = g; out_rgb[3 * o + 2] = b; }
+    if (out_rgba) reinterpret_cast<uint32_t*>(out_rgba)[o] = to_byte(r) | (to_byte(g) << 8) | (to_byte(b) << 16) | 0xFF000000u;   // R, G, B, A = 255 in memory order
 }
 
-__global__ __launch_bounds__(kBlock) void k_blend(const double* __restrict__ acc, const uint8_t* __restrict__ touched, uint32_t acc_stride, uint32_t n_pix_host, const PixCount* counts,
-                                                   uint32_t first, int32_t spp, const uint32_t* __restrict__ out_index, double* __restrict__ out) {
-    uint32_t n_pix = n_pix_host;                                    // all pixels of the chunk, or its window of the frame's active list (k_classify)
-    if (counts) { const uint32_t n_active = counts->n_pix; n_pix = n_active > first ? (n_active - first < n_pix_host ? n_active - first : n_pix_host) : 0u; }
-    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
-        double r = 0.0, g = 0.0, b = 0.0;                          // Array.average: sum from Zero in sample order, then DivideByInt
-        for (int s = 0; s < spp; ++s) {
-            const size_t i = (size_t)s * n_pix + p;
-            if (!touched[i]) continue;                             // a sample that hit nothing is Colour.Zero: x + 0 = x
-            r += acc[i]; g += acc[(size_t)acc_stride + i]; b += acc[2 * (size_t)acc_stride + i];
+// k_resolve: every pixel of the chunk's window of the active list gets the mean of its samples, summed from Zero in sample order and
+// divided once (JitteredSampling.blendPixels, Image.fs:112-116: Array.average = sum, then DivideByInt, CommonTypes.fs:43-48); with
+// block_pos the launch also writes Colour.Zero for the pixels of every block k_classify finished.  Each pixel of the frame is
+// written once, as FP64 RGB and / or as RGBA8 bytes.
+__global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs a) {
+    uint32_t n_pix = a.n_pix_host;                                  // all pixels of the chunk, or its window of the frame's active list (k_classify)
+    if (a.counts) { const uint32_t n_active = a.counts->n_pix; n_pix = n_active > a.first ? (n_active - a.first < a.n_pix_host ? n_active - a.first : a.n_pix_host) : 0u; }
+    const double spp = (double)a.spp;
+    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += gridDim.x * kBlock) {
+        double r = 0.0, g = 0.0, b = 0.0;
+        for (int s = 0; s < a.spp; ++s) {
+            const size_t i = (size_t)s * n_pix + q;
+            r += a.acc[i]; g += a.acc[(size_t)a.acc_stride + i]; b += a.acc[2 * (size_t)a.acc_stride + i];
         }
-        const size_t o = out_index ? out_index[p] : p;
-        out[3 * o] = r / (double)spp; out[3 * o + 1] = g / (double)spp; out[3 * o + 2] = b / (double)spp;
+        const uint32_t al = a.first + q;                            // position in the active list -> position in the original pixel list
+        const uint32_t p = a.pos_block ? a.pos_block[al >> 6] * 64u + (al & 63u) : al;
+        write_pixel(a.out_rgb, a.out_rgba, a.pixel_ids ? (size_t)a.pixel_ids[p] : (size_t)p, r / spp, g / spp, b / spp);
+    }
+    if (a.block_pos) {                                              // one wave per finished block: Colour.Zero for its 64 pixels
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t blk = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; blk < a.n_blocks_total; blk += gridDim.x * (kBlock / 64)) {
+            if (a.block_pos[blk] >= 0) continue;
+            const uint32_t p = blk * 64u + lane;
+            write_pixel(a.out_rgb, a.out_rgba, a.pixel_ids ? (size_t)a.pixel_ids[p] : (size_t)p, 0.0, 0.0, 0.0);
+        }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_blend_corner(const double* __restrict__ acc, const uint8_t* __restrict__ touched, uint32_t acc_stride, uint32_t w, uint32_t h,
-                                                          const uint32_t* __restrict__ out_index, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_resolve_corner(const double* __restrict__ acc, uint32_t acc_stride, uint32_t w, uint32_t h,
+                                                            const uint32_t* __restrict__ out_index, double* __restrict__ out_rgb, uint8_t* __restrict__ out_rgba) {
     const uint32_t n = w * h, cs = w + 1;
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
         const uint32_t y = p / w, x = p - y * w;
         const uint32_t c[4] = {y * cs + x, y * cs + x + 1, (y + 1) * cs + x, (y + 1) * cs + x + 1};   // Image.fs:139
         double r = 0.0, g = 0.0, b = 0.0;                          // Seq.average: sum in corner order, / 4
-        for (int k = 0; k < 4; ++k) { if (!touched[c[k]]) continue; r += acc[c[k]]; g += acc[(size_t)acc_stride + c[k]]; b += acc[2 * (size_t)acc_stride + c[k]]; }
-        const size_t o = out_index ? out_index[p] : p;
-        out[3 * o] = r / 4.0; out[3 * o + 1] = g / 4.0; out[3 * o + 2] = b / 4.0;
+        for (int k = 0; k < 4; ++k) { r += acc[c[k]]; g += acc[(size_t)acc_stride + c[k]]; b += acc[2 * (size_t)acc_stride + c[k]]; }
+        write_pixel(out_rgb, out_rgba, out_index ? (size_t)out_index[p] : (size_t)p, r / 4.0, g / 4.0, b / 4.0);
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene Sg, const double* __restrict__ o, const double* __restrict__ d, uint32_t n,
-                                                           int32_t* hit, double* t, double* p, double* nrm, double* colour, RenderCounters* rc) {
+                                                           int32_t* hit, double* t, double* p, double* nrm, double* colour, unsigned long long* overflow_count) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
     const uint32_t B = 64u / (uint32_t)S.lane_fold, n_batches = (n + B - 1) / B;
@@ -1923,13 +1907,13 @@ __global__ __launch_bounds__(kBlock) void k_debug_closest(DevScene Sg, const dou
             p[3 * i] = sf.p.x; p[3 * i + 1] = sf.p.y; p[3 * i + 2] = sf.p.z;
             nrm[3 * i] = sf.n.x; nrm[3 * i + 1] = sf.n.y; nrm[3 * i + 2] = sf.n.z;
             colour[3 * i] = col[0]; colour[3 * i + 1] = col[1]; colour[3 * i + 2] = col[2];
-            if (overflow) atomicAdd(&rc->csg_overflow, 1ull);
+            if (overflow) atomicAdd(overflow_count, 1ull);
         }
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const double* __restrict__ o, const double* __restrict__ d,
-                                                           const double* __restrict__ max_dist, uint32_t n, int32_t* blocked, RenderCounters* rc) {
+                                                           const double* __restrict__ max_dist, uint32_t n, int32_t* blocked, unsigned long long* overflow_count) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Scene S = scene_view(Sg);
     const uint32_t B = 64u / (uint32_t)S.lane_fold, n_batches = (n + B - 1) / B;
@@ -1941,7 +1925,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
         if (q.active) { r = {o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]}; q.max_dist = max_dist[i]; }
         bool overflow;
         trace<true, true>(S, r, q, lds, overflow);
-        if (q.active) { blocked[i] = q.blocked ? 1 : 0; if (overflow) atomicAdd(&rc->csg_overflow, 1ull); }
+        if (q.active) { blocked[i] = q.blocked ? 1 : 0; if (overflow) atomicAdd(overflow_count, 1ull); }
     }
 }
 
@@ -1992,51 +1976,44 @@ static TailKernel tail_variant(int v) {
 // ============================================================================================ launchers
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
-void launch_closest(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, uint32_t* hit_list, uint8_t* touched, int bounce, uint32_t tail_threshold, ChunkCounters* cc, RenderCounters* rc) {
-    const ClosestArgs a{S, gen, rays, hits, hit_list, touched, cc, rc, bounce, tail_threshold};
+void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, uint32_t tail_threshold, FrameCounters* fc) {
+    const ClosestArgs a{S, rays, hits, hit_list, fc, bounce, tail_threshold};
     if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
     else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
 void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
-                  uint32_t acc_stride, int bounce, int max_depth, ChunkCounters* cc, RenderCounters* rc) {
-    auto k = shade_variant(L.variant);
-    const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, cc, rc, acc_stride, bounce, max_depth};
-    hipLaunchKernelGGL(k, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
+                  uint32_t acc_stride, int bounce, int max_depth, FrameCounters* fc) {
+    const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, fc, acc_stride, bounce, max_depth};
+    hipLaunchKernelGGL(shade_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
-void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint8_t* touched, uint32_t acc_stride, int max_depth,
-                    ChunkCounters* cc, RenderCounters* rc) {
-    const PrimaryArgs a{S, gen, next, acc, touched, cc, rc, acc_stride, max_depth};
+void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint32_t acc_stride, int max_depth, FrameCounters* fc) {
+    const PrimaryArgs a{S, gen, next, acc, fc, acc_stride, max_depth};
     hipLaunchKernelGGL(primary_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
-void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, uint8_t* block_active, uint32_t* segment_count, uint32_t* active_ids,
-                     uint32_t* active_pos, PixCount* counts, double* out, int whole, double jitter_extent, RenderCounters* rc) {
-    const ClassifyArgs a{S, gen_list, block_active, segment_count, out, rc, whole, jitter_extent};
-    const uint32_t n_blocks = gen_list.n_pix / 64u, n_runs = (n_blocks + kClassifyRun - 1) / kClassifyRun, n_segments = (n_blocks + kSegmentBlocks - 1) / kSegmentBlocks;
-    hipLaunchKernelGGL(k_classify, dim3(blocks_for(n_runs * 64u, L.grid)), dim3(kBlock), 0, L.stream, a);
-    const CompactArgs cmp{gen_list.pixel_ids + gen_list.pix_base, block_active, segment_count, active_ids, active_pos, counts, n_blocks, n_segments};
-    hipLaunchKernelGGL(k_compact, dim3(n_segments), dim3(kBlock), 0, L.stream, cmp);
+void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list, const ClassifyOut& out, double jitter_extent, uint32_t epoch, FrameCounters* fc) {
+    const ClassifyArgs a{S, gen_list, out, fc, jitter_extent, epoch};
+    const uint32_t n_blocks = gen_list.n_pix / 64u;
+    hipLaunchKernelGGL(k_classify, dim3((n_blocks + kClassifyBlock - 1u) / kClassifyBlock), dim3(kClassifyBlock), 0, L.stream, a);
 }
 void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
-                 int max_depth, uint32_t threshold, ChunkCounters* cc, RenderCounters* rc) {
-    const TailArgs a{S, gen, {rays_even, rays_odd}, acc, cc, rc, acc_stride, max_depth, threshold};
+                 int max_depth, uint32_t threshold, FrameCounters* fc, int first_bounce) {
+    const TailArgs a{S, gen, {rays_even, rays_odd}, acc, fc, acc_stride, max_depth, threshold, first_bounce};
     hipLaunchKernelGGL(tail_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
-void launch_blend(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t n_pix, const PixCount* counts, uint32_t first, int32_t spp, const uint32_t* out_index, double* out_rgb) {
-    hipLaunchKernelGGL(k_blend, dim3(blocks_for(n_pix, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, n_pix, counts, first, spp, out_index, out_rgb);
+void launch_resolve(const Launch& L, const ResolveArgs& a) {
+    const uint32_t work = a.block_pos ? (a.n_blocks_total * 64u > a.n_pix_host ? a.n_blocks_total * 64u : a.n_pix_host) : a.n_pix_host;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, L.grid * 4)), dim3(kBlock), 0, L.stream, a);
 }
-void launch_blend_corner(const Launch& L, const double* acc, const uint8_t* touched, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb) {
-    hipLaunchKernelGGL(k_blend_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, touched, acc_stride, w, h, out_index, out_rgb);
-}
-void launch_reduce_stats(const Launch& L, RenderCounters* slots, uint32_t n_slots) {
-    hipLaunchKernelGGL(k_reduce_stats, dim3((n_slots + 63) / 64), dim3(64), 0, L.stream, slots, n_slots);
+void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba) {
+    hipLaunchKernelGGL(k_resolve_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, w, h, out_index, out_rgb, out_rgba);
 }
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n, int32_t* hit, double* t,
-                          double* p, double* nrm, double* colour, RenderCounters* rc) {
-    hipLaunchKernelGGL(k_debug_closest, dim3(blocks_for(n, L.grid)), dim3(kBlock), L.lds_bytes, L.stream, S, o, d, n, hit, t, p, nrm, colour, rc);
+                          double* p, double* nrm, double* colour, unsigned long long* overflow) {
+    hipLaunchKernelGGL(k_debug_closest, dim3(blocks_for(n, L.grid)), dim3(kBlock), L.lds_bytes, L.stream, S, o, d, n, hit, t, p, nrm, colour, overflow);
 }
 void launch_debug_blocked(const Launch& L, const DevScene& S, const double* o, const double* d, const double* max_dist, uint32_t n,
-                          int32_t* blocked, RenderCounters* rc) {
-    hipLaunchKernelGGL(k_debug_blocked, dim3(blocks_for(n, L.grid)), dim3(kBlock), L.lds_bytes, L.stream, S, o, d, max_dist, n, blocked, rc);
+                          int32_t* blocked, unsigned long long* overflow) {
+    hipLaunchKernelGGL(k_debug_blocked, dim3(blocks_for(n, L.grid)), dim3(kBlock), L.lds_bytes, L.stream, S, o, d, max_dist, n, blocked, overflow);
 }
 
 } // namespace ftk

@@ -28,6 +28,7 @@
 #ifndef FUNCTRACER_HIP_H
 #define FUNCTRACER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -120,19 +121,22 @@ typedef struct ft_stats {
     int32_t  n_launches;
     int32_t  n_chunks;
     uint64_t hits_total;     /* hits shaded over all bounces                                   */
-    uint64_t algorithmic_bytes_closest; /* the k_closest share of algorithmic_bytes            */
-    uint64_t algorithmic_bytes_shade;   /* the k_shade share                                   */
+    uint64_t algorithmic_bytes_closest; /* the k_closest share of algorithmic_bytes (bounces >= 1) */
+    uint64_t algorithmic_bytes_shade;   /* the k_shade share (bounces >= 1)                    */
     uint64_t rays_tail;      /* reflection rays followed by the tail kernel (handed over + spawned inside it) */
     uint64_t rays_primary_culled; /* primary rays (part of rays_primary) resolved as misses per 64-pixel block: the block's ray
                                    * bundle cannot reach any object, so they were never generated one by one          */
     uint64_t algorithmic_bytes_primary; /* the k_primary (fused bounce 0) share of algorithmic_bytes                          */
+    uint64_t rays_shadow_primary;  /* the part of rays_shadow cast by hits of primary rays (traced inside k_primary)          */
+    uint64_t rays_reflect_primary; /* the part of rays_reflect spawned by hits of primary rays                                */
 } ft_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */
 int32_t ft_abi_version(void);
 /* device_ids: HIP device ordinals; n_devices must be >= 1 (0 ⇒ FT_ERR_NO_DEVICE: no CPU path).  With several
  * ordinals the scene is replicated on each device and every ft_render splits its region into 8-row bands dealt
- * round-robin over them, one host thread per device, no exchange between devices (bands meet in out_rgb). */
+ * round-robin over them, one host thread per device, no exchange between devices: every device copies its bands (whole rows of
+ * the frame) straight into the caller's buffer. */
 int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out);
 void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);
@@ -140,7 +144,7 @@ const char* ft_last_error(const ft_context* ctx);
  * CSG; default 32), "csg_auto_grow" (default 1: a blocking ft_render (and the ft_debug_* ray queries) whose hit lists overflow doubles that capacity, re-commits and renders the
  * frame again instead of returning FT_ERR_OVERFLOW; the error remains for lists that stop fitting in the LDS and for ft_render_enqueue), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around every
  * k_closest / k_shade launch, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
- * cannot reach any object are finished before any ray is generated), "tail_rays" (a bounce starting with fewer rays is finished by the tail
+ * cannot reach any object are finished before any ray is generated; the bundle is bounded from the jitter pattern handed to ft_render, whatever its range), "tail_rays" (a bounce starting with fewer rays is finished by the tail
  * kernel in one launch; 0 = never; default 262144), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
@@ -192,14 +196,32 @@ int32_t ft_render(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t 
 
 int32_t ft_fetch_frame(ft_context* ctx, double* out_rgb);
 
-/* Pipelined rendering on a one-device context, for hosts that render frame after frame (an animation, a progressive preview):
+/* The same frame as Image.write consumes it (Image.fs:35-44): RGBA8, one byte per channel = truncate(clamp01(c) * 255) (Image.fs:36,
+ * Math.fs:12-16; NaN -> 0), alpha 255, res_v x res_h x 4 bytes, row 0 = top.  The quantisation runs on the device in the kernel
+ * that averages the samples, so 4 instead of 24 bytes per pixel cross the PCIe link; bytes are identical to ft_quantise_rgba8 of
+ * ft_render's frame.  After ft_render_rgba8 / ft_render_enqueue_rgba8 the frame in HBM is the RGBA8 one: fetch it with
+ * ft_fetch_frame_rgba8 (ft_fetch_frame then returns FT_ERR_STATE, and vice versa). */
+int32_t ft_render_rgba8(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp,
+                        const double* jitter_xy, int32_t max_depth, uint64_t seed,
+                        const ft_rect* tiles, int32_t n_tiles, uint8_t* out_rgba, ft_stats* stats);
+int32_t ft_fetch_frame_rgba8(ft_context* ctx, uint8_t* out_rgba);
+
+/* Page-locked host memory (hipHostMalloc) for frames handed to ft_render / ft_fetch_frame*: the copy out of HBM is then one DMA
+ * without the runtime's staging through its own pinned buffers.  Optional: any host pointer works. */
+void* ft_host_alloc(size_t bytes);
+void  ft_host_free(void* p);
+
+/* Pipelined rendering, for hosts that render frame after frame (an animation, a progressive preview):
  * ft_render_enqueue queues a frame exactly as ft_render(out_rgb = NULL) would and returns without waiting, so the host prepares
- * the next frame while this one runs; at most two frames are in flight (queuing a third first waits for the oldest).
+ * the next frame while this one runs; at most two frames are in flight (queuing a third first waits for the oldest).  On a context
+ * over several devices every device queues its bands on its own stream; ft_render_wait waits for all of them and sums their statistics.
  * ft_render_wait blocks until everything queued has finished, reports the statistics of the LAST frame, and leaves in
  * ft_get_kernel_times the stage times and launch counts summed over all frames since the previous wait.  The frame buffer holds
  * the last frame (ft_fetch_frame).  The reference's own flow is synchronous (Program.fs:63-64): ft_render stays that way. */
 int32_t ft_render_enqueue(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                           int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles);
+int32_t ft_render_enqueue_rgba8(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                                int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles);
 int32_t ft_render_wait(ft_context* ctx, ft_stats* stats);
 
 /* Closest hit of single rays through the device path (Scene.intersectScene, Scene.fs:118, after
@@ -210,6 +232,10 @@ int32_t ft_debug_closest(ft_context* ctx, const double* origins, const double* d
 /* lightIsBocked (Scene.fs:119-121) for single rays. */
 int32_t ft_debug_blocked(ft_context* ctx, const double* origins, const double* dirs,
                          const double* max_dist, int64_t n, int32_t* blocked);
+
+/* getColourForRay (Shading.fs:131-139) for single rays through the device path: slightOffset, closest hit, shadow queries, the
+ * shaders of Program.fs:59 and up to max_depth reflection bounces, exactly as a frame's samples are shaded.  rgb = n x 3. */
+int32_t ft_debug_colour(ft_context* ctx, const double* origins, const double* dirs, int64_t n, int32_t max_depth, double* rgb);
 
 /* Host-logic test hooks (no device work): a context that can build, flatten and BSP-compile a scene
  * but whose render/debug calls fail with FT_ERR_NO_DEVICE; flattened-scene sizes

@@ -72,3 +72,48 @@ def assert_frames_match(got, want, rtol=PIXEL_RTOL, what=""):
 
 def deg(x):
     return x * (math.pi / 180.0)
+
+
+def build_described_scene(b, objects, lights):
+    """Build a scene given as data (tests/golden/known_answers.json, "hand_derived_shading") in builder `b`.
+    object: {"prim": name, "xf": [[kind, v(, degrees)], ...] (first listed applied first), "material": {...}, "ignore_light": bool}
+            or {"csg": op, "a": object, "b": object}."""
+    def node(o):
+        if "csg" in o:
+            n = getattr(b, o["csg"])(node(o["a"]), node(o["b"]))
+        else:
+            n = b.primitive(PRIMS[o["prim"]])
+        if o.get("xf"):
+            n = b.transform([(t[0], t[1], deg(t[2])) if t[0] == "rotate" else (t[0], t[1]) for t in o["xf"]], n)
+        if "material" in o:
+            n = b.material(n, **o["material"])
+        if o.get("ignore_light"):
+            n = b.ignore_light(n)
+        return n
+    b.clear()
+    b.set_objects(b.group([node(o) for o in objects]))
+    for l in lights:
+        if l["kind"] == "directional":
+            b.add_directional(l["dir"], l["colour"])
+        elif l["kind"] == "point":
+            b.add_positional(l["pos"], l["falloff"], l["colour"])
+        else:
+            b.add_soft_directional(l["dir"], l["samples"], deg(l["scatter"]), l["colour"])
+    b.commit()
+
+
+def check_shading_case(b, case, rtol=1e-9):
+    """Shade the case's rays with getColourForRay through builder `b` (oracle or device) and compare with its hand-derived colours."""
+    build_described_scene(b, case["objects"], case["lights"])
+    want = np.array([[float(v) for v in r["rgb"]] for r in case["rays"]])
+    got = b.colour_for_ray([r["o"] for r in case["rays"]], [r["d"] for r in case["rays"]], max_depth=case.get("max_depth", 8))
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{case['name']}: NaN pattern {got} vs {want}"
+    ok = np.isclose(got, want, rtol=rtol, atol=1e-15) | np.isnan(want)
+    assert ok.all(), f"{case['name']}: got {got.tolist()}, hand-derived {want.tolist()} ({case['cites']})"
+
+
+def csg_pair(b, op):
+    """A (unit sphere at the origin) `op` B (unit sphere at (0,0,1)): the scene of "hand_derived_csg"."""
+    b.clear()
+    b.set_objects(b.group([getattr(b, op)(b.primitive(PRIMS["sphere"]), b.translate((0, 0, 1), b.primitive(PRIMS["sphere"])))]))
+    b.commit()

@@ -31,6 +31,45 @@ def test_known_answers_through_the_device_path(hip, golden):
             assert np.allclose(n[0], case["n"], atol=1e-12), case["name"]
 
 
+def _shading_cases():
+    import json
+    with open(os.path.join(H.ROOT, "tests", "golden", "known_answers.json")) as f:
+        return json.load(f)["hand_derived_shading"]["cases"]
+
+
+@pytest.mark.parametrize("case", _shading_cases(), ids=lambda c: c["name"])
+def test_hand_derived_shading_on_the_device(hip, case):
+    """Closed-form colours derived from Shading.fs / Light.fs / Csg.fs (tests/tools/derive_shading_answers.py; no oracle involved):
+    unclamped Lambert, the three regimes of the specular power, attenuation and the shadow test, the per-light unlit colour, the
+    per-light mirror bounce and the recursion limit, shaded by getColourForRay on the device (ft_debug_colour)."""
+    H.check_shading_case(hip, case)
+
+
+def test_hand_derived_csg_tables_on_the_device(hip, golden):  # Csg.fs:19-55, 59-72
+    for op in ("union", "intersect", "subtract", "exclude"):
+        cases = [c for c in golden["hand_derived_csg"]["cases"] if c["op"] == op]
+        H.csg_pair(hip, op)
+        hit, t, p, n, _ = hip.closest([c["o"] for c in cases], [c["d"] for c in cases])
+        for k, c in enumerate(cases):
+            assert bool(hit[k]) == c["hit"], (op, c["why"])
+            if c["hit"]:
+                assert t[k] == pytest.approx(c["t"], abs=1e-12) and np.allclose(n[k], c["n"], atol=1e-12), (op, c["why"], t[k], n[k])
+
+
+def test_debug_colour_equals_the_rendered_pixel(hip):
+    """ft_debug_colour is the frame's own shading path fed with explicit rays: the colour of the ray through a pixel centre equals
+    that pixel of a 1-sample frame with a zero jitter offset (the device contracts the ray's a*b+c into FMAs, the oracle's
+    ray_through_pixel used here does not: 1e-12)."""
+    p = _load("hollow-sphere")
+    p.lower(hip)
+    w, h = 64, 48
+    frame, _ = hip.render(p.camera, w, h, 1, np.zeros((1, 2)))
+    o, d = zip(*[O.ray_through_pixel(p.camera, w, h, x, y) for y in range(0, h, 5) for x in range(0, w, 7)])
+    got = hip.colour_for_ray(np.array(o), np.array(d))
+    want = np.array([frame[y, x] for y in range(0, h, 5) for x in range(0, w, 7)])
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+
+
 def test_csg_hollow_shell_known_answer(hip, golden):
     g = golden["hand_derived"]["csg_hollow_shell"]
     hip.clear()
@@ -397,6 +436,109 @@ def test_config5_resolution_properties(hip):
     assert np.array_equal(bright, 2.0 * full)
 
 
+def _band_sample_parity(hip, name, w, h, spp, stride, seed=ft.DEFAULT_SEED):
+    """Render the whole frame on the device, every `stride`th 8-row band of it with the oracle, and compare those rows."""
+    from functracer_amd import tiling
+    p = _load(name)
+    p.lower(hip)
+    orc = O.Oracle()
+    p.lower(orc)
+    jit = ft.jitter_pattern(spp)
+    got, st = hip.render(p.camera, w, h, spp, jit, seed=seed)
+    sample = tiling.bands_for_rank(w, h, 0, stride)
+    want = np.zeros_like(got)
+    _, ost = orc.render(p.camera, w, h, spp, jit, seed=seed, tiles=sample, out=want)
+    rows_got, rows_want = tiling.pack_bands(got, sample), tiling.pack_bands(want, sample)
+    worst = H.assert_frames_match(rows_got, rows_want, what=f"{name} {w}x{h}x{spp} on every {stride}th band")
+    assert worst < 1e-6
+    return got, st, ost
+
+
+@pytest.mark.parametrize("name,spp,stride", [("hollow-sphere", 1, 1), ("bunny", 4, 2), ("bunny", 16, 6), ("night-house-det", 16, 10), ("night-house", 16, 10)])
+def test_full_size_configs_against_the_oracle(hip, name, spp, stride):
+    """BASELINE configs 2-4 (and the headline frame) at their full 1920x1080 size: the device frame against the oracle on an
+    interleaved band sample of the same frame (the whole frame for hollow-sphere), 1e-4 contract, < 1e-6 observed."""
+    _, st, ost = _band_sample_parity(hip, name, 1920, 1080, spp, stride)
+    assert st["rays_primary"] == 1920 * 1080 * spp and st["csg_overflow"] == 0
+    if stride == 1:
+        assert st["rays_reference_equivalent"] == ost["rays_traced"]
+
+
+def test_config5_full_size_64_samples(hip):
+    """BASELINE config 5 as named: 3840x2160 x 64 spp (a multi-chunk frame on one GPU).  The union of the eight ranks' band shares
+    equals the single-context frame bit for bit, the ray accounting adds up over the shares, and the oracle agrees on a thin band
+    sample (every 54th 8-row band = 40 rows x 3840 pixels x 64 samples)."""
+    from functracer_amd import tiling
+    w, h, spp = 3840, 2160, 64
+    full, st, _ = _band_sample_parity(hip, "bunny", w, h, spp, 54)
+    assert st["n_chunks"] > 1 and st["rays_primary"] == w * h * spp
+    p = _load("bunny")
+    jit = ft.jitter_pattern(spp)
+    tiled = np.zeros_like(full)
+    shares = []
+    for r in range(8):
+        _, sr = hip.render(p.camera, w, h, spp, jit, tiles=tiling.bands_for_rank(w, h, r, 8), out=tiled)
+        shares.append(sr)
+    assert np.array_equal(tiled, full), "union of the eight band shares differs from the whole frame"
+    for key in ("rays_primary", "rays_shadow", "rays_reflect", "hits_primary", "rays_reference_equivalent"):
+        assert sum(s[key] for s in shares) == st[key], key
+    work = [s["rays_traced"] for s in shares]
+    assert max(work) < 1.15 * (sum(work) / 8), f"band shares uneven: {work}"
+
+
+def test_rgba8_frames_are_the_quantised_fp64_frames(hip):
+    """ft_render_rgba8 quantises on the device (Image.fs:36): bytes identical to ft_quantise_rgba8 of the FP64 frame, whole frame,
+    tiles and corner sampling, including a NaN pixel and the pixels of finished blocks; the two frame formats do not mix."""
+    for name, spp in (("bunny", 3), ("hollow-sphere", 2), ("moon", 1)):
+        p = _load(name)
+        p.lower(hip)
+        jit = ft.jitter_pattern(spp)
+        f64, st = hip.render(p.camera, 256, 192, spp, jit)
+        u8, st8 = hip.render_rgba8(p.camera, 256, 192, spp, jit)
+        assert np.array_equal(u8, ft.quantise_rgba8(f64)) and st8["rays_traced"] == st["rays_traced"]
+        with pytest.raises(ft.FtError):
+            hip.fetch_frame(np.zeros_like(f64))                     # the frame in HBM is the RGBA8 one now
+        tiles = [(8, 16, 64, 40), (128, 0, 56, 24)]
+        part = np.full((192, 256, 4), 7, dtype=np.uint8)
+        hip.render_rgba8(p.camera, 256, 192, spp, jit, tiles=tiles, out=part)
+        mask = np.zeros((192, 256), dtype=bool)
+        for (x0, y0, tw, th) in tiles:
+            mask[y0:y0 + th, x0:x0 + tw] = True
+        assert np.array_equal(part[mask], u8[mask]) and (part[~mask] == 7).all()
+        corner64, _ = hip.render(p.camera, 96, 64, 0, None)
+        corner8, _ = hip.render_rgba8(p.camera, 96, 64, 0, None)
+        assert np.array_equal(corner8, ft.quantise_rgba8(corner64))
+    # NaN passes the clamp and becomes byte 0 (Math.fs:12-16, Image.fs:36): the fractional-power specular case
+    case = [c for c in _shading_cases() if c["name"] == "specular_negative_base_fractional_exponent_is_nan"][0]
+    H.build_described_scene(hip, case["objects"], case["lights"])
+    cam = ft.make_camera((0, 0, -3), (0, 0, 0), (0, 1, 0), H.deg(40.0), 1.0)
+    f64, _ = hip.render(cam, 64, 64, 1, np.zeros((1, 2)))
+    u8, _ = hip.render_rgba8(cam, 64, 64, 1, np.zeros((1, 2)))
+    assert np.isnan(f64).any() and np.array_equal(u8, ft.quantise_rgba8(f64))
+
+
+def test_jitter_offsets_outside_the_unit_disc(hip):
+    """The jitter pattern is the caller's (the reference draws it in the unit disc, Jitter.fs:15-21): offsets beyond one pixel
+    widen the bundle k_classify bounds instead of cutting silhouettes off."""
+    p = _load("bunny")
+    p.lower(hip)
+    orc = O.Oracle()
+    p.lower(orc)
+    jit = np.array([[1.5, -1.5], [-1.5, 1.5], [2.75, 0.25], [0.0, -3.5]])
+    got, st = hip.render(p.camera, 320, 240, 4, jit)
+    want, _ = orc.render(p.camera, 320, 240, 4, jit)
+    assert st["rays_primary_culled"] > 0
+    assert H.assert_frames_match(got, want, what="jitter offsets up to 3.5 pixels") < 1e-6
+    hip.set_option("classify_pixels", 0)
+    try:
+        plain, _ = hip.render(p.camera, 320, 240, 4, jit)
+    finally:
+        hip.set_option("classify_pixels", 1)
+    assert np.array_equal(plain, got)
+    wild, stw = hip.render(p.camera, 320, 240, 1, np.array([[1e9, 0.0]]))   # absurd offsets: classification stands down
+    assert stw["rays_primary_culled"] == 0 and np.isfinite(wild).all()
+
+
 def test_unclipped_bvh_fast_mode_stays_within_the_contract(hip):
     """Non-default mode: bspMesh depth is ignored and the original (unclipped) triangles are traced through the BVH.
     The reference-shaped clipped BSP stays the parity mode; this one must stay inside the 1e-4 pixel contract."""
@@ -487,8 +629,10 @@ def test_pixel_block_classification_changes_no_pixel(hip, name):
     assert s0["rays_primary_culled"] == 0
     if name != "hollow-sphere":                                   # its camera sits inside the shell: every block sees it
         assert s1["rays_primary_culled"] > 0 and st1["rays_primary_culled"] > 0
-    for key in ("rays_primary", "rays_shadow", "rays_reflect", "rays_traced", "hits_primary", "hits_total", "rays_reference_equivalent"):
+    for key in ("rays_primary", "rays_shadow", "rays_reflect", "hits_primary", "hits_total", "rays_reference_equivalent"):
         assert s0[key] == s1[key] and st0[key] == st1[key], key
+    # rays_traced counts what was generated: the primaries of finished blocks are exactly the difference
+    assert s0["rays_traced"] == s1["rays_traced"] + s1["rays_primary_culled"] and st0["rays_traced"] == st1["rays_traced"] + st1["rays_primary_culled"]
 
 
 def _grid_of_pairs(b, nx, ny, reflect=0.4):

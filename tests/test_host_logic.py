@@ -173,7 +173,7 @@ def test_abi_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.ft_abi_version.restype = C.c_int32
-    assert lib.ft_abi_version() == 1
+    assert lib.ft_abi_version() == 2
     # no CPU backend: zero devices is an error, not an oracle-backed context (SURVEY 8b proposed one; the product has none)
     h = C.c_void_p()
     assert lib.ft_create(None, 0, C.byref(h)) == -2 and not h.value

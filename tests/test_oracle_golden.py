@@ -135,3 +135,30 @@ def test_reflection_is_added_once_per_light():                # Shading.fs:119-1
     # 1 light: 0.5 * glow; 2 lights: reflection traced per light, and the unlit glow colour is itself added per light
     assert np.allclose(one, 0.5 * np.array([0.25, 0.5, 1.0]))
     assert np.allclose(two, 2 * 0.5 * (2 * np.array([0.25, 0.5, 1.0])))
+
+
+def _shading_cases():
+    import json
+    import os
+    with open(os.path.join(H.ROOT, "tests", "golden", "known_answers.json")) as f:
+        return json.load(f)["hand_derived_shading"]["cases"]
+
+
+@pytest.mark.parametrize("case", _shading_cases(), ids=lambda c: c["name"])
+def test_hand_derived_shading(case):                          # Shading.fs:33-139, derivations in tests/tools/derive_shading_answers.py
+    H.check_shading_case(O.Oracle(), case)
+
+
+def test_hand_derived_csg_tables(golden):                     # Csg.fs:19-55, 59-72
+    by_op = {}
+    for case in golden["hand_derived_csg"]["cases"]:
+        by_op.setdefault(case["op"], []).append(case)
+    assert sorted(by_op) == ["exclude", "intersect", "subtract", "union"]
+    for op, cases in by_op.items():
+        o = O.Oracle()
+        H.csg_pair(o, op)
+        hit, t, p, n, _ = o.closest([c["o"] for c in cases], [c["d"] for c in cases])
+        for k, c in enumerate(cases):
+            assert bool(hit[k]) == c["hit"], (op, c["why"])
+            if c["hit"]:
+                assert t[k] == pytest.approx(c["t"], abs=1e-12) and np.allclose(n[k], c["n"], atol=1e-12), (op, c["why"], t[k], n[k])

@@ -26,9 +26,9 @@ for name, spp in CASES:
             best = st
     kt = ctx.kernel_times()
     row = {"ms": round(best["kernel_ms"], 3), "mrays_s": round(best["rays_traced"] / best["kernel_ms"] / 1e3, 1), "rays": best["rays_traced"],
-           "closest_ms": round(kt["closest"]["ms"], 3), "shade_ms": round(kt["shade"]["ms"], 3), "blend_ms": round(kt["blend"]["ms"], 3)}
+           "primary_ms": round(kt["primary"]["ms"], 3), "closest_ms": round(kt["closest"]["ms"], 3), "shade_ms": round(kt["shade"]["ms"], 3), "other_ms": round(kt["other"]["ms"], 3)}
     out[f"{name}x{spp}"] = row
-    print(f"{name:18s} x{spp:<3d} {row['ms']:9.3f} ms {row['mrays_s']:10.1f} Mrays/s  closest {row['closest_ms']:.3f} shade {row['shade_ms']:.3f} blend {row['blend_ms']:.3f}", flush=True)
+    print(f"{name:18s} x{spp:<3d} {row['ms']:9.3f} ms {row['mrays_s']:10.1f} Mrays/s  primary {row['primary_ms']:.3f} closest {row['closest_ms']:.3f} shade+tail {row['shade_ms']:.3f} other {row['other_ms']:.3f}", flush=True)
 if len(sys.argv) > 1:
     os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(R, "gpurun_out", f"scenes_{sys.argv[1]}.json"), "w"), indent=1)
