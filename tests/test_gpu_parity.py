@@ -371,10 +371,14 @@ def test_corner_sampling(hip, name):
 
 def test_multi_device_context_equals_single_device(hip):
     """ft_create with several device ordinals: the scene is replicated and frames are band-partitioned inside the
-    library.  With one GPU on the test box the same ordinal is listed three times (three sub-contexts)."""
+    library, every device copying its bands (whole rows) straight into the caller's frame.  On a box with one GPU the same
+    ordinal is listed three times (three sub-contexts); with more GPUs visible, distinct ordinals are used."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    ordinals = list(range(min(n_dev, 4))) if n_dev > 1 else [0, 0, 0]
     p = _load("night-house")
     p.lower(hip)
-    multi = ft.Context(device=[0, 0, 0])
+    multi = ft.Context(device=ordinals)
     p.lower(multi)
     jit = ft.jitter_pattern(2)
     want, st1 = hip.render(p.camera, 320, 180, 2, jit, seed=3)
@@ -387,6 +391,18 @@ def test_multi_device_context_equals_single_device(hip):
     part = np.full_like(want, -1.0)
     multi.render(p.camera, 320, 180, 2, jit, seed=3, tiles=[(16, 8, 64, 40)], out=part)
     assert np.array_equal(part[8:48, 16:80], want[8:48, 16:80]) and (part[:8] == -1.0).all()
+    # pipelined frames on every device (ft_render_enqueue on a multi-device context), FP64 and RGBA8
+    for _ in range(3):
+        multi.render_enqueue(p.camera, 320, 180, 2, jit, seed=3)
+    stq = multi.wait()
+    assert np.array_equal(multi.fetch_frame(np.zeros_like(want)), want)
+    for key in ("rays_primary", "rays_shadow", "rays_reflect", "rays_traced", "hits_primary", "rays_reference_equivalent"):
+        assert stq[key] == st1[key], key
+    multi.render_enqueue(p.camera, 320, 180, 2, jit, seed=3, rgba8=True)
+    multi.wait()
+    assert np.array_equal(multi.fetch_frame_rgba8(np.zeros((180, 320, 4), dtype=np.uint8)), ft.quantise_rgba8(want))
+    u8, _ = multi.render_rgba8(p.camera, 320, 180, 2, jit, seed=3)
+    assert np.array_equal(u8, ft.quantise_rgba8(want))
     multi.close()
 
 

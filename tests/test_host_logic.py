@@ -179,6 +179,50 @@ def test_abi_exports_every_declared_symbol():
     assert lib.ft_create(None, 0, C.byref(h)) == -2 and not h.value
 
 
+def test_fsharp_binding_matches_the_header():
+    """INTEGRATION.md's F# shim cannot be compiled here (no .NET toolchain): at least keep it consistent with the C header.  Every
+    DllImport names an exported function with the header's number of arguments, and every function of the render path is bound."""
+    hdr = open(os.path.join(H.ROOT, "include", "functracer_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(ft_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    doc = open(os.path.join(H.ROOT, "INTEGRATION.md")).read()
+    fs = "\n".join(re.findall(r"```fsharp\n(.*?)```", doc, flags=re.S))
+    imports = {}
+    for m in re.finditer(r"\[<DllImport\(Lib\)>\]\s*extern\s+\w+\s+(ft_[a-z0-9_]+)\s*\(([^)]*)\)", fs, flags=re.S):
+        args = m.group(2).strip()
+        imports[m.group(1)] = 0 if args == "" else len(args.split(","))
+    assert len(imports) >= 30
+    for name, n in imports.items():
+        assert name in protos, f"{name} is not declared in functracer_hip.h"
+        assert protos[name] == n, f"{name}: {n} arguments in the F# binding, {protos[name]} in the header"
+    test_hooks = {n for n in protos if n.startswith("ft_debug_")} | {"ft_create_host_only"}
+    assert set(protos) - test_hooks <= set(imports), sorted(set(protos) - test_hooks - set(imports))
+    for used in re.findall(r"\b(ft_[a-z0-9_]+)\s*\(", re.sub(r"\[<DllImport.*", "", fs)):     # every call in the shim's code is bound
+        assert used in imports, used
+    # the pieces the round-1 shim lacked: the Transform lowering, Focus, soft-light units
+    assert "let rec toFt (t: Transform)" in fs and "Composed ts -> List.collect toFt ts" in fs
+    assert "cam.focus with" in fs and "f.apetureAngularSize" in fs
+    # struct layouts: same number of fields as the C structs
+    def c_fields(name):
+        body = re.search(r"typedef struct " + name + r"\s*\{(.*?)\}\s*" + name + ";", hdr, flags=re.S).group(1)
+        n = 0
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            arr = re.search(r"\[(\d+)\]", decl)
+            n += (int(arr.group(1)) if arr else 1) * len(decl.split(","))
+        return n
+    def fs_fields(name):
+        body = re.search(r"type " + name + r"\s*=\s*\{(.*?)\}", fs, flags=re.S).group(1)
+        return len(re.findall(r"\w+\s*:", body))
+    for c_name, f_name in (("ft_transform", "FtTransform"), ("ft_material", "FtMaterial"), ("ft_camera", "FtCamera"), ("ft_rect", "FtRect"), ("ft_stats", "FtStats")):
+        assert c_fields(c_name) == fs_fields(f_name), (c_name, c_fields(c_name), fs_fields(f_name))
+
+
 def test_product_library_does_not_link_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", ft.HIP_LIB], capture_output=True, text=True).stdout + subprocess.run(["nm", "-D", ft.HIP_LIB], capture_output=True, text=True).stdout

@@ -2,12 +2,12 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE), collected as
 MI355X_MICROARCH.md §HBM prescribes: separate --pmc passes, values in KiB, and on gfx950 FETCH_SIZE
 under-reports coalesced streaming reads (exactly 1/2 for 16 B/lane).  This path reads 8 B/lane, an
-uncalibrated width; it was calibrated while k_blend still read every accumulator (exactly 24*spp B per pixel):
-factor 1.979 and 1.9998 in two separate passes (profiles/r01_d_*, r01_j_pmc_traffic_bunny.json), WRITE_SIZE
-exact (1.0004).  The read side is therefore doubled (--read-scale 2.0); k_blend's write (24 B per pixel) is
-still checked in every run as `write_ratio`.
+uncalibrated width, so every run calibrates itself on the one kernel whose bytes are known exactly: k_resolve
+reads 24 B per active sample + 4 B of pixel id per listed pixel + 4 B per block of the maps, and writes 24 B per pixel
+of the frame.  Round 1 found the read factor 1.979 / 1.9998 the same way on its k_blend; the factor measured here is
+applied to every kernel's FETCH_SIZE (`read_scale`), WRITE_SIZE is used as it is (`write_ratio` says how exact it is).
 
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --pixels 2073600 --spp 16
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --pixels 2073600 --spp 16 --active-pixels N --frames F
 """
 import argparse
 import csv
@@ -37,18 +37,22 @@ def main():
     ap.add_argument("--pixels", type=int, required=True)
     ap.add_argument("--spp", type=int, required=True)
     ap.add_argument("--read-scale", type=float, default=2.0, help="FETCH_SIZE correction for this path's coalesced 8 B/lane reads")
-    ap.add_argument("--active-pixels", type=int, default=0, help="pixels k_classify kept (ft_stats: (rays_primary - rays_primary_culled) / spp); they also cost 8 B of list each")
-    ap.add_argument("--frames", type=int, default=7, help="frames rendered by the profiled command (steps + warmup)")
+    ap.add_argument("--active-pixels", type=int, default=0, help="pixels k_classify kept (ft_stats: (rays_primary - rays_primary_culled) / spp)")
+    ap.add_argument("--frames", type=int, default=7, help="frames rendered by the profiled command (every ft_render / enqueue)")
+    ap.add_argument("--f64-frames", type=int, default=None, help="how many of them are FP64 frames (the others are RGBA8: 4 B per pixel out)")
     args = ap.parse_args()
     fetch, write = load(args.fetch_dir, "FETCH_SIZE"), load(args.write_dir, "WRITE_SIZE")
-    # Every pixel of a frame is written exactly once, 24 B, by k_classify (blocks that see nothing) or k_blend (the rest), and every
-    # active pixel costs 8 B of list: the known byte count that checks WRITE_SIZE in every run.
-    known_write = (24.0 * args.pixels + 8.0 * args.active_pixels) * args.frames
-    out_write = sum(write.get("k_blend", [])) + sum(write.get("k_classify", []))
-    read_scale = args.read_scale
-    out = {"calibration": {"read_scale": read_scale, "read_scale_source": "k_blend full-accumulator passes r01_d / r01_j: 1.979, 1.9998",
-                           "known_output_bytes_all_frames": known_write, "WRITE_SIZE_k_blend_plus_k_classify_all_frames": out_write,
-                           "write_ratio": out_write / known_write}}
+    f64 = args.frames if args.f64_frames is None else args.f64_frames
+    known_write = args.pixels * (24.0 * f64 + 4.0 * (args.frames - f64))   # k_resolve writes every pixel of the frame once
+    known_read = (24.0 * args.spp * args.active_pixels + 4.0 * args.pixels + 8.0 * args.pixels / 64.0) * args.frames
+    got_write, got_read = sum(write.get("k_resolve", [])), sum(fetch.get("k_resolve", []))
+    read_scale = known_read / got_read if got_read > 0 else args.read_scale
+    note = "measured on k_resolve in this run"
+    if not 1.5 <= read_scale <= 2.5:
+        read_scale, note = args.read_scale, f"k_resolve gave {known_read / max(1.0, got_read):.3f}: outside 1.5..2.5, fell back to --read-scale"
+    out = {"calibration": {"read_scale": read_scale, "read_scale_source": note, "k_resolve_known_read_bytes_all_frames": known_read, "k_resolve_FETCH_SIZE_all_frames": got_read,
+                           "k_resolve_known_write_bytes_all_frames": known_write, "k_resolve_WRITE_SIZE_all_frames": got_write,
+                           "write_ratio": got_write / known_write if known_write else None}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
