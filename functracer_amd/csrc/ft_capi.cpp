@@ -707,7 +707,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         if ((rc = ensure(c, c->d_block_pos, n_blocks * 4)) != FT_OK) return rc;
         if ((rc = ensure(c, c->d_pos_block, n_blocks * 4)) != FT_OK) return rc;
         if (c->d_wave_counts.bytes < n_waves * 4 || c->classify_epoch >= 0x3FFFFEu) {   // entries are tagged with the frame's epoch and never cleared in between
-            if ((rc = ensure(c, c->d_wave_counts, std::max<size_t>(n_waves * 4, 4096))) != FT_OK) return rc;
+            if ((rc = ensure(c, c->d_wave_counts, std::max<size_t>(n_waves * 4, 4096) + 4096 * 4 + 2048 * 64)) != FT_OK) return rc;   // (+ room for the diagnostic build's stamps)
             FT_HIP(c, hipMemsetAsync(c->d_wave_counts.p, 0, c->d_wave_counts.bytes, c->stream));
             c->classify_epoch = 0;
         }
@@ -1058,6 +1058,13 @@ static int32_t debug_colour(ft_context* c, const double* origins, const double* 
     for (int k = 0; k < ftk::kStatStripes; ++k) ovf += tail.stats[k].csg_overflow;
     if (ovf) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
     return FT_OK;
+}
+
+/* Diagnostic builds (-DFT_STAMPS): the s_memrealtime stamps k_classify's workgroups left behind (8 per workgroup). */
+int32_t ft_debug_classify_stamps(ft_context* c, unsigned long long* out, int32_t n_groups) {
+    if (!c || !out || n_groups < 1 || n_groups > 2048 || !c->d_wave_counts.p) return FT_ERR_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return FT_ERR_HIP;
+    return hipMemcpy(out, c->d_wave_counts.as<uint32_t>() + 4096, (size_t)n_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? FT_OK : FT_ERR_HIP;
 }
 
 int32_t ft_debug_scene_info(ft_context* c, int64_t out[12]) {
