@@ -51,6 +51,7 @@ def hip_lib():
                                          _capi.c_double_p, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p]
         lib.ft_debug_blocked.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, _capi.c_int32_p]
         lib.ft_debug_colour.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, C.c_int32, _capi.c_double_p]
+        lib.ft_get_commit_times.argtypes = [C.c_void_p, _capi.c_double_p]
         lib.ft_debug_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.ft_debug_slice.argtypes = [_capi.c_double_p] * 4 + [_capi.c_int32_p, _capi.c_double_p, _capi.c_int32_p]
         lib.ft_render_enqueue.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32, C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32]
@@ -297,6 +298,12 @@ class Context(SceneBuilder):
         rgb = np.zeros((o.shape[0], 3))
         self._check(self._lib.ft_debug_colour(self._ctx, _capi.dptr(o), _capi.dptr(d), o.shape[0], max_depth, _capi.dptr(rgb)))
         return rgb
+
+    def commit_times(self):
+        """ft_get_commit_times of the last commit: host flatten, device BVH builds, uploads (ms) and the tallest device-built tree."""
+        ms = np.zeros(4)
+        self._check(self._lib.ft_get_commit_times(self._ctx, _capi.dptr(ms)))
+        return {"flatten_ms": float(ms[0]), "device_bvh_ms": float(ms[1]), "upload_ms": float(ms[2]), "device_bvh_height": int(ms[3])}
 
     def scene_info(self):
         out = (C.c_int64 * 12)()

@@ -45,6 +45,8 @@ struct ft_context {
     fth::SceneGraph graph;
     fth::FlatScene flat;
     bool committed = false;
+    int bvh_builder = 1;            // who builds the exact BVH of top-level-Leaf meshes: 1 = the device (ft_bvh.hip), 0 = the host's median split
+    double commit_ms[4] = {0, 0, 0, 0};   // last ft_scene_commit: flatten on the host, device BVH builds, uploads + the rest, BVH height (not a time)
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
@@ -258,6 +260,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
     if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
+    if (!std::strcmp(key, "bvh_builder")) { if (value < 0 || value > 1) return FT_ERR_INVALID; c->bvh_builder = (int)value; c->committed = false; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
     return FT_ERR_INVALID;
@@ -363,14 +366,37 @@ static int32_t upload_scene(ft_context* c);
 
 int32_t ft_scene_commit(ft_context* c) {
     if (!c) return FT_ERR_INVALID;
-    int32_t rc = c->graph.flatten(c->flat, c->err);
-    if (rc != FT_OK) return rc;
-    if (c->host_only) { c->committed = true; return FT_OK; }
-    if ((rc = upload_scene(c)) != FT_OK) return rc;
-    for (ft_context* p : c->peers) {                                // replicate the flattened scene on every other device
-        p->flat = c->flat;
-        if ((rc = upload_scene(p)) != FT_OK) { c->err = p->err; return rc; }
+    using clock = std::chrono::steady_clock;
+    auto ms_since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
+    for (double& v : c->commit_ms) v = 0.0;
+    // A device context builds the exact BVH of top-level-Leaf meshes on the device ("bvh_builder" = 1, the default): the flattener
+    // reserves the ranges, upload_scene fills them.  A build the device refuses (a tree too deep for the traversal stacks) falls
+    // back to the host's median split, once, for the whole scene.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        c->graph.device_bvh = !c->host_only && c->bvh_builder == 1 && attempt == 0;
+        auto t0 = clock::now();
+        int32_t rc = c->graph.flatten(c->flat, c->err);
+        c->commit_ms[0] += ms_since(t0);
+        if (rc != FT_OK) return rc;
+        if (c->host_only) { c->committed = true; return FT_OK; }
+        t0 = clock::now();
+        rc = upload_scene(c);
+        for (ft_context* p : c->peers) {                            // replicate the flattened scene on every other device
+            if (rc != FT_OK) break;
+            p->flat = c->flat;
+            if ((rc = upload_scene(p)) != FT_OK) c->err = p->err;
+            c->commit_ms[1] += p->commit_ms[1];
+        }
+        c->commit_ms[2] += ms_since(t0) - c->commit_ms[1];
+        if (rc == FT_ERR_BUILD && c->graph.device_bvh) continue;    // refused by the device builder: the host builds it
+        return rc;
     }
+    return FT_ERR_BUILD;
+}
+
+int32_t ft_get_commit_times(ft_context* c, double ms[4]) {
+    if (!c || !ms) return FT_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) ms[k] = c->commit_ms[k];
     return FT_OK;
 }
 
@@ -400,6 +426,25 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_fc, sizeof(ftk::FrameCounters))) != FT_OK) return rc;
     FT_HIP(c, hipStreamSynchronize(c->stream));
+    {   // the BVHs the flattener left to the device (ft_bvh.hip), straight into the ranges reserved in the arrays just uploaded
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t tallest = 0;
+        for (const fth::FlatScene::BvhJob& j : f.bvh_jobs) {
+            const ftk::LbvhTarget t{c->d_tris.as<double>(), j.first_global, j.n, c->d_nodes.as<ftd::BspNode>(), j.node_base, c->d_bleaves.as<ftd::BspLeaf>(), j.leaf_base,
+                                    c->d_tri_orig.as<uint32_t>(), j.tri_base, c->d_wide.as<double>(), j.wide_base, c->d_coarse.as<float>() + 6 * (size_t)j.coarse_first, j.coarse_count};
+            uint32_t height = 0;
+            FT_HIP(c, ftk::build_lbvh(c->stream, t, &height));
+            // height 0: a non-finite coordinate; > 40: deeper than the packet walk's 64-entry stack allows (3 entries per 4-wide level)
+            if (height == 0 || height > 40) { c->err = "device BVH build refused (non-finite vertex or a tree deeper than 40 levels): the host builder takes over"; return FT_ERR_BUILD; }
+            tallest = std::max(tallest, height);
+        }
+        if (!f.bvh_jobs.empty()) {
+            c->commit_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            c->commit_ms[3] = tallest;
+            if ((int32_t)tallest + 1 > c->flat.stack_capacity) c->flat.stack_capacity = (int32_t)tallest + 1;   // per-lane node stacks of the incoherent walk (LDS)
+            if (lane_fold_for(c->flat) == 0) { c->err = "scene needs more than 160 KiB of LDS per workgroup for CSG lists / BSP stacks even with 4 live lanes per wave"; return FT_ERR_UNSUPPORTED; }
+        }
+    }
     ftk::DevScene& S = c->dev_scene;
     S.leaves = c->d_leaves.as<double>(); S.m2w = c->d_m2w.as<double>();
     S.materials = c->d_materials.as<ftd::Material>(); S.lights = c->d_lights.as<ftd::Light>(); S.textures = c->d_textures.as<ftd::Texture>();

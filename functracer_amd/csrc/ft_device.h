@@ -148,6 +148,20 @@ struct ResolveArgs {
 void launch_resolve(const Launch& L, const ResolveArgs& a);
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
 void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba);
+// Device-side BVH build (ft_bvh.hip): a linear BVH over triangles [first_global, first_global + n) of `tris`, written into the ranges
+// the flattener reserved for the mesh: n - 1 BspNodes at node_base, (n - 1) + n BspLeafs at leaf_base, n sorted triangle records and
+// list indices at tri_base, n - 1 4-wide nodes at wide_base, coarse_count (<= 64) float boxes at coarse.  *height = height of the
+// binary tree in nodes, 0 when the mesh holds a non-finite coordinate (nothing usable was written).
+struct LbvhTarget {
+    double* tris; uint32_t first_global, n;
+    ftd::BspNode* nodes; uint32_t node_base;
+    ftd::BspLeaf* leaves; uint32_t leaf_base;
+    uint32_t* tri_orig; uint32_t tri_base;
+    double* wide; uint32_t wide_base;
+    float* coarse; uint32_t coarse_count;
+};
+hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height);
+
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,
                           int32_t* hit, double* t, double* p, double* nrm, double* colour, unsigned long long* overflow);

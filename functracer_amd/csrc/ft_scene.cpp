@@ -175,7 +175,7 @@ struct Flattener {
     uint32_t mesh_for(int32_t node_id, const double* tris, int64_t n, int32_t depth) {
         if (node_id >= 0) { auto it = mesh_of_node.find(node_id); if (it != mesh_of_node.end()) return it->second; }
         ftd::Mesh m{};
-        int32_t rc = build_bsp(tris, n, depth, out, m, err);
+        int32_t rc = build_bsp(tris, n, depth, out, m, err, g.device_bvh);
         if (rc != FT_OK) { status = rc; return 0; }
         out.meshes.push_back(m);
         {
@@ -638,7 +638,7 @@ struct BspBuilder {
 
 } // namespace
 
-int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatScene& out, ftd::Mesh& mesh, std::string& err) {
+int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatScene& out, ftd::Mesh& mesh, std::string& err, bool device_bvh) {
     if (n_tris < 0 || (n_tris > 0 && !tris_abc) || depth < 0) { err = "bad mesh arguments"; return FT_ERR_INVALID; }
     std::vector<Tri3> ts((size_t)n_tris);
     for (int64_t i = 0; i < n_tris; ++i) {
@@ -651,13 +651,33 @@ int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatSce
     mesh.root = root; mesh.n_source_tris = (uint32_t)n_tris; mesh.max_depth = b.max_depth;
     mesh.bvh_root = INT32_MIN;
     int32_t wide_root = INT32_MIN;
-    if (root < 0) {                                                             // top-level Leaf: add the exact BVH for closest / any-hit queries
+    bool deferred = false;
+    if (root < 0 && device_bvh && ts.size() >= 8 && ts.size() < (1u << 28)) {
+        // top-level Leaf, BVH built on the device after the upload: reserve its ranges here (ft_bvh.hip documents what lands where)
+        const uint32_t n = (uint32_t)ts.size();
+        FlatScene::BvhJob job{(uint32_t)out.meshes.size(), out.bsp_leaves[(size_t)~root].first_tri, n, (uint32_t)out.nodes.size(), (uint32_t)out.bsp_leaves.size(),
+                              (uint32_t)(out.tris.size() / 9), (uint32_t)(out.wide.size() / ftd::kWideNodeDoubles), (uint32_t)(out.coarse_boxes.size() / 6), 64u};
+        out.nodes.resize(out.nodes.size() + (n - 1), ftd::BspNode{});
+        out.bsp_leaves.resize(out.bsp_leaves.size() + (2 * (size_t)n - 1), ftd::BspLeaf{0, 0});
+        out.tris.resize(out.tris.size() + 9 * (size_t)n, 0.0);
+        out.tri_orig.resize(out.tri_orig.size() + n, 0u);
+        out.wide.resize(out.wide.size() + (size_t)ftd::kWideNodeDoubles * (n - 1), 0.0);
+        for (uint32_t k = 0; k < job.coarse_count; ++k) { const float all[6] = {-3e38f, -3e38f, -3e38f, 3e38f, 3e38f, 3e38f}; out.coarse_boxes.insert(out.coarse_boxes.end(), all, all + 6); }   // until the build: everything
+        out.bvh_jobs.push_back(job);
+        out.bvh_nodes += n - 1; out.bvh_leaves += 2 * (int64_t)n - 1; out.bvh_tris += n;
+        mesh.bvh_root = (int32_t)job.node_base;
+        wide_root = (int32_t)job.wide_base;
+        out.mesh_wide.push_back(wide_root);
+        out.mesh_coarse.push_back(job.coarse_first); out.mesh_coarse.push_back(job.coarse_count);
+        deferred = true;
+    } else if (root < 0) {                                                      // top-level Leaf: add the exact BVH for closest / any-hit queries
         const size_t n0 = out.nodes.size(), l0 = out.bsp_leaves.size(), t0 = out.tris.size() / 9;
         mesh.bvh_root = b.bvh_for_leaf(ts, out.bsp_leaves[(size_t)~root].first_tri);
         wide_root = mesh.bvh_root >= 0 ? b.widen(mesh.bvh_root) : INT32_MIN;
         out.bvh_nodes += (int64_t)(out.nodes.size() - n0); out.bvh_leaves += (int64_t)(out.bsp_leaves.size() - l0); out.bvh_tris += (int64_t)(out.tris.size() / 9 - t0);
         if (mesh.bvh_root >= 0 && (int32_t)b.bvh_depth + 1 > out.stack_capacity) out.stack_capacity = (int32_t)b.bvh_depth + 1;
     }
+    if (deferred) return FT_OK;
     out.mesh_wide.push_back(wide_root);
     {   // <= 64 boxes that together hold every triangle of the mesh: one level of the binary tree (BVH of a top-level Leaf, or the BSP itself)
         const int32_t top = root < 0 ? mesh.bvh_root : root;

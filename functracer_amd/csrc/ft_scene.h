@@ -58,6 +58,9 @@ struct FlatScene {
     bool any_reflective = false;
     bool any_texture = false;
     bool mesh_under_csg = false;
+    // Meshes whose exact BVH is built on the device after the upload (ft_bvh.hip): the flattener only reserves their ranges.
+    struct BvhJob { uint32_t mesh, first_global, n, node_base, leaf_base, tri_base, wide_base, coarse_first, coarse_count; };
+    std::vector<BvhJob> bvh_jobs;
 };
 
 struct SceneGraph {
@@ -69,6 +72,9 @@ struct SceneGraph {
     // its ORIGINAL triangles.  The reference clips triangles at BSP planes; unclipped triangles give the same surface but the
     // hit arithmetic differs in the last bits, so pixels may differ at the 1e-12 level (and on silhouette ties).
     bool mesh_unclipped_bvh = false;
+    // Who builds the exact BVH of top-level-Leaf meshes: true = the device (linear BVH, ft_bvh.hip; device contexts' default),
+    // false = the host's recursive median split (host-only contexts, and the fallback when a device build is refused).
+    bool device_bvh = false;
 
     bool valid(int32_t id) const { return id >= 0 && id < (int32_t)nodes.size(); }
     // Returns FT_OK or a negative ft_status with err set.
@@ -77,7 +83,7 @@ struct SceneGraph {
 
 // BspMesh.compile (BspMesh.fs:51-65) on the host: appends nodes / leaves / clipped triangles to
 // the flat arrays and returns the root reference (>= 0 branch node, < 0 ~leaf) via mesh.
-int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatScene& out, ftd::Mesh& mesh, std::string& err);
+int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatScene& out, ftd::Mesh& mesh, std::string& err, bool device_bvh = false);
 
 // Triangle.slice (Triangle.fs:24-41) exposed for the known-answer tests of the product's own builder.
 int32_t slice_triangle(const double p0[3], const double n[3], const double tri[9],

@@ -146,7 +146,8 @@ const char* ft_last_error(const ft_context* ctx);
  * k_closest / k_shade launch, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
  * cannot reach any object are finished before any ray is generated; the bundle is bounded from the jitter pattern handed to ft_render, whatever its range), "tail_rays" (a bounce starting with fewer rays is finished by the tail
  * kernel in one launch; 0 = never; default 262144), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
- * differ from the reference-shaped clipped BSP in the last bits).  Scene-affecting options need a new ft_scene_commit. */
+ * differ from the reference-shaped clipped BSP in the last bits), "bvh_builder" (1 = default: the exact BVH of top-level-Leaf meshes is a linear BVH built on the
+ * device at commit; 0: the host's recursive median split).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
 
 /* ---- scene graph builder (Scene.fs:8-53) ------------------------------------------------- */
@@ -179,8 +180,12 @@ int32_t ft_scene_add_soft_directional(ft_context* ctx, const double dir[3], int3
                                       double scatter_rad, const double colour[3]);
 int32_t ft_scene_add_positional(ft_context* ctx, const double pos[3], const double falloff[3],
                                 const double colour[3]);
-/* Flatten the graph, build BSP trees (BspMesh.compile, BspMesh.fs:51-65) and upload to HBM. */
+/* Flatten the graph, build BSP trees (BspMesh.compile, BspMesh.fs:51-65) and upload to HBM.  The exact BVH that stands in for the
+ * linear scan of a `bspMesh 0` (BspMesh.fs:95-97) is built on the device ("bvh_builder" = 1, default) or by the host (0). */
 int32_t ft_scene_commit(ft_context* ctx);
+/* Wall time of the last ft_scene_commit in ms: [0] flatten on the host (includes the host's BVH builds with "bvh_builder" = 0),
+ * [1] BVH builds on the device, [2] uploads and the rest; [3] is not a time: the height of the tallest device-built tree. */
+int32_t ft_get_commit_times(ft_context* ctx, double ms[4]);
 
 /* ---- render (Program.fs:54-64) ----------------------------------------------------------- */
 /* res_h x res_v is Image.Resolution (Image.fs:28).  jitter_xy = spp x 2 offsets, the ONE pattern

@@ -555,6 +555,67 @@ def test_jitter_offsets_outside_the_unit_disc(hip):
     assert stw["rays_primary_culled"] == 0 and np.isfinite(wild).all()
 
 
+def test_device_built_bvh_equals_host_built_bvh(hip):
+    """The exact BVH of a `bspMesh 0` is built on the device by default (linear BVH, ft_bvh.hip) and by the host's median split
+    with "bvh_builder" = 0.  Both stand in for the reference's linear scan (BspMesh.fs:95-97): closest hits (ties included: many
+    coincident triangles, whose hits must go to the lowest list index), shadow queries and frames agree bit for bit with each
+    other, and with the oracle's brute force within the contract."""
+    rng = np.random.default_rng(11)
+    centres = rng.normal(size=(3000, 1, 3)) * 0.8
+    tris = centres + rng.normal(size=(3000, 3, 3)) * 0.08
+    tris[100:400] = tris[100]                                       # 300 coincident triangles: one Morton cell, equal t on every hit
+    o, d = H.random_rays(30000, seed=5, origin_scale=2.5, spread=0.8)
+    md = np.abs(np.random.default_rng(6).normal(size=o.shape[0])) * 4.0
+    cam = ft.make_camera((0, 0.5, -4), (0, 0, 0), (0, 1, 0), H.deg(50.0), 1.0)
+    jit = ft.jitter_pattern(2)
+    results = {}
+    try:
+        for builder in (0, 1):
+            hip.set_option("bvh_builder", builder)
+            hip.clear()
+            hip.set_objects(hip.group([hip.material(hip.bsp_mesh(0, tris.reshape(-1, 9)), colour=(0.9, 0.5, 0.2), shineyness=4.0)]))
+            hip.add_directional((1, -2, 1), (1, 1, 1))
+            hip.add_positional((2, 3, -2), (1, 0.1, 0.01), (0.5, 0.5, 1.0))
+            hip.commit()
+            ct = hip.commit_times()
+            assert (ct["device_bvh_height"] > 0) == (builder == 1) and (ct["device_bvh_ms"] > 0) == (builder == 1)
+            results[builder] = (hip.closest(o, d), hip.blocked(o, d, md), hip.render(cam, 320, 240, 2, jit)[0])
+    finally:
+        hip.set_option("bvh_builder", 1)
+    (c0, b0, f0), (c1, b1, f1) = results[0], results[1]
+    for x, y in zip(c0, c1):
+        assert np.array_equal(x, y)
+    assert np.array_equal(b0, b1) and np.array_equal(f0, f1)
+    orc = O.Oracle()
+    orc.clear()
+    orc.set_objects(orc.group([orc.material(orc.bsp_mesh(0, tris.reshape(-1, 9)), colour=(0.9, 0.5, 0.2), shineyness=4.0)]))
+    orc.add_directional((1, -2, 1), (1, 1, 1))
+    orc.add_positional((2, 3, -2), (1, 0.1, 0.01), (0.5, 0.5, 1.0))
+    orc.commit()
+    H.assert_hits_match(c1, orc.closest(o, d), what="device-built BVH")
+    assert np.array_equal(b1, orc.blocked(o, d, md))
+    want, _ = orc.render(cam, 320, 240, 2, jit)
+    assert H.assert_frames_match(f1, want, what="device-built BVH frame") < 1e-6
+
+
+def test_device_bvh_refuses_a_non_finite_mesh_and_the_host_takes_over(hip):
+    """A mesh with a NaN vertex gets no BVH at all from either builder (the reference's linear scan is what remains): the device
+    builder refuses it, the commit falls back to the host flattener, and frames still match the oracle."""
+    rng = np.random.default_rng(3)
+    tris = (rng.normal(size=(40, 1, 3)) * 0.5 + rng.normal(size=(40, 3, 3)) * 0.2)
+    tris[7, 1, 2] = np.nan
+    cam = ft.make_camera((0, 0, -4), (0, 0, 0), (0, 1, 0), H.deg(40.0), 1.0)
+    frames = []
+    for b in (hip, O.Oracle()):
+        b.clear()
+        b.set_objects(b.group([b.bsp_mesh(0, tris.reshape(-1, 9))]))
+        b.add_directional((0, -1, 1), (1, 1, 1))
+        b.commit()
+        frames.append(b.render(cam, 96, 96, 1, np.zeros((1, 2)))[0])
+    assert hip.commit_times()["device_bvh_height"] == 0            # the scene in HBM is the host-built one
+    assert H.assert_frames_match(frames[0], frames[1], what="NaN vertex") < 1e-6
+
+
 def test_unclipped_bvh_fast_mode_stays_within_the_contract(hip):
     """Non-default mode: bspMesh depth is ignored and the original (unclipped) triangles are traced through the BVH.
     The reference-shaped clipped BSP stays the parity mode; this one must stay inside the 1e-4 pixel contract."""
