@@ -268,7 +268,7 @@ class Context(SceneBuilder):
         ms = np.zeros(5)
         n = np.zeros(5, dtype=np.int32)
         self._check(self._lib.ft_get_kernel_times(self._ctx, _capi.dptr(ms), n.ctypes.data_as(_capi.c_int32_p)))
-        names = ["other", "closest", "shade", "resolve", "primary"]   # "other": the fill, k_classify (and k_resolve unless "timing" = 2); "shade" includes k_tail
+        names = ["other", "closest", "shade", "resolve", "primary"]   # "other": the fill, k_classify (and k_resolve unless "timing" = 2); "shade": k_bounce, all levels; "closest": unused
         return {k: {"ms": float(ms[i]), "launches": int(n[i])} for i, k in enumerate(names)}
 
     def closest(self, origins, dirs):
@@ -318,9 +318,8 @@ def rays_handled_by(kernel, st):
     generated = st["rays_primary"] - st["rays_primary_culled"]
     if kernel == "primary":                                         # fused bounce 0: every generated primary ray + the shadow rays of its hits
         return generated + st["rays_shadow_primary"]
-    if kernel == "closest":                                         # reflection rays of the staged bounces
-        return st["rays_reflect"] - min(st["rays_reflect"], st["rays_tail"])
-    return st["rays_shadow"] - st["rays_shadow_primary"]            # shadow rays of bounces >= 1 (k_shade and k_tail)
+    # k_bounce ("shade"): the reflection rays of every level >= 1 and the shadow rays of their hits
+    return st["rays_reflect"] + st["rays_shadow"] - st["rays_shadow_primary"]
 
 
 def debug_slice(p0, n, tri):

@@ -19,8 +19,7 @@
 
 namespace ftk {
 int occupancy_blocks_primary(size_t lds_bytes, int variant);
-int occupancy_blocks_closest(size_t lds_bytes, int variant);
-int occupancy_blocks_shade(size_t lds_bytes, int variant);
+int occupancy_blocks_bounce(size_t lds_bytes, int variant);
 }
 
 struct DeviceBuf {
@@ -52,13 +51,13 @@ struct ft_context {
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
     int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
-    int64_t tail_rays = 262144;      // a bounce that starts with fewer rays is finished by k_tail (0 = never)
+    bool level_hint = true;         // launch only as many k_bounce levels as the previous frame of the same signature had (+ 1); 0: always max_depth
 
     // scene in HBM
     DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_block_pos, d_pos_block, d_wave_counts, d_wide, d_mesh_wide, d_coarse;
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
-    DeviceBuf d_rays[2], d_hits, d_hit_list, d_acc, d_out, d_out8, d_pixels, d_jitter, d_fc, d_dbg_in, d_dbg_out;
+    DeviceBuf d_rays[2], d_acc, d_out, d_out8, d_pixels, d_jitter, d_fc, d_dbg_in, d_dbg_out;
     uint32_t classify_epoch = 0;    // tags the entries k_classify's waves publish in d_wave_counts (cleared only when it wraps or the buffer grows)
     int64_t ray_capacity = 0, acc_capacity = 0;
     // Per-frame host state.  Two slots, so that one frame can be queued while the previous one still runs (ft_render_enqueue).
@@ -68,12 +67,22 @@ struct ft_context {
         std::vector<Span> spans;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
         FrameTail* h_tail = nullptr;            // pinned landing place of the frame's statistic stripes and k_classify's error word
+        uint32_t* h_rays = nullptr;             // ... and of the last chunk's rays per bounce (ChunkCounters::n_rays)
+        int levels_launched = 0, last_bounce = 0;
+        uint64_t signature = 0;                 // what the frame rendered (scene, size, samples, depth, threshold): keys the staged-launch hint
         bool pending = false;
         uint64_t rays_primary = 0; int64_t n_pix_total = 0; int32_t spp = 0, n_launches = 0, n_chunks = 0, timing = 1, format = 0; bool classify = false;
         std::chrono::steady_clock::time_point wall0;
     };
     FrameSlot slots[2];
     int slot_turn = 0;
+    // Levels of the reflection tree worth launching: the host cannot know how deep the rays of a frame go without waiting, and a
+    // k_bounce launch that finds no rays still costs a few microseconds.  It launches as many levels as the previous frame of the
+    // same signature had rays in, plus one; the last one launched follows whatever it still spawns to the end inside the kernel,
+    // so the frame is complete however deep it goes.  -1: no history, launch max_depth levels.
+    int staged_hint = -1;
+    uint64_t staged_signature = 0;
+    uint64_t commit_serial = 0;
     bool csg_auto_grow = true;   // ft_render: double csg_mesh_capacity and render again when a hit list overflows
     bool accum_open = false;        // kernel times are being summed over pipelined frames (reset by the next enqueue after a wait)
     // pixel list of the last render, cached across calls with the same resolution and tiles
@@ -130,14 +139,12 @@ ftk::RayBuf ray_view(const DeviceBuf& b, int64_t cap) {
     return r;
 }
 
-// Per-sample accumulators for every frame; ray / hit wavefront buffers only for scenes with reflective materials (bounce >= 1).
+// Per-sample accumulators for every frame; the ray wavefront buffers only for scenes with reflective materials (bounce >= 1).
 int32_t ensure_frame_buffers(ft_context* c, int64_t cap, bool reflective) {
     int32_t rc;
     if (cap > c->acc_capacity) { if ((rc = ensure(c, c->d_acc, (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
     if (!reflective || cap <= c->ray_capacity) return FT_OK;
     for (int i = 0; i < 2; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_hits, (size_t)cap * 16)) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_hit_list, (size_t)cap * 4)) != FT_OK) return rc;
     c->ray_capacity = cap;
     return FT_OK;
 }
@@ -240,10 +247,10 @@ void ft_destroy(ft_context* c) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos, &c->d_pos_block, &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
-                             &c->d_rays[0], &c->d_rays[1], &c->d_hits, &c->d_hit_list, &c->d_acc, &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc,
+                             &c->d_rays[0], &c->d_rays[1], &c->d_acc, &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
-        for (auto& f : c->slots) { if (f.h_tail) { (void)hipHostFree(f.h_tail); f.h_tail = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
+        for (auto& f : c->slots) { if (f.h_tail) { (void)hipHostFree(f.h_tail); f.h_tail = nullptr; } if (f.h_rays) { (void)hipHostFree(f.h_rays); f.h_rays = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -259,7 +266,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
-    if (!std::strcmp(key, "tail_rays")) { if (value < 0 || value > 0x7FFFFFFF) return FT_ERR_INVALID; c->tail_rays = value; for (ft_context* p : c->peers) p->tail_rays = value; return FT_OK; }
+    if (!std::strcmp(key, "level_hint")) { c->level_hint = value != 0; for (ft_context* p : c->peers) p->level_hint = value != 0; return FT_OK; }
     if (!std::strcmp(key, "bvh_builder")) { if (value < 0 || value > 1) return FT_ERR_INVALID; c->bvh_builder = (int)value; c->committed = false; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
@@ -455,6 +462,7 @@ static int32_t upload_scene(ft_context* c) {
     S.wide = c->d_wide.as<double>(); S.mesh_wide = c->d_mesh_wide.as<int32_t>();
     S.item_pc = c->d_item_pc.as<uint32_t>();
     S.coherent_waves = c->coherent_waves ? 1 : 0;
+    S.n_simd = c->n_cu * 4;
     S.n_items = (int32_t)f.item_pc.size() - 1; S.n_cull_rows = f.cull_bundle ? (int32_t)(f.cull_rows.size() / 3) : -1;
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
@@ -462,6 +470,7 @@ static int32_t upload_scene(ft_context* c) {
     S.shadow_rays_per_hit = 0;
     for (auto& l : f.lights) S.shadow_rays_per_hit += (l.kind == ftd::LT_SOFT) ? l.samples : 1;   // Shading.fs:24-42
     c->committed = true;
+    ++c->commit_serial; c->staged_hint = -1;
     return FT_OK;
 }
 
@@ -768,13 +777,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
     if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
     ftk::Launch Lp{c->stream, c->n_cu * ftk::occupancy_blocks_primary(lds, variant), lds, variant};
-    ftk::Launch Lc{c->stream, c->n_cu * ftk::occupancy_blocks_closest(lds, variant), lds, variant};
-    ftk::Launch Ls{c->stream, c->n_cu * ftk::occupancy_blocks_shade(lds, variant), lds, variant};
-    ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_tail(lds, variant), lds, variant};
+    ftk::Launch Lb{c->stream, c->n_cu * ftk::occupancy_blocks_bounce(lds, variant), lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
-    ftk::HitBuf hb{c->d_hits.as<double>(), reinterpret_cast<uint32_t*>(c->d_hits.as<double>() + c->ray_capacity),
-                   reinterpret_cast<uint32_t*>(c->d_hits.as<double>() + c->ray_capacity) + c->ray_capacity};
 
     // A blocking call retires whatever is in flight first; a deferred one only the frame whose slot it is about to reuse.
     if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < kStages; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
@@ -801,7 +806,10 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         if (boundary && b) spans.push_back(Span{boundary, b, kind});
         boundary = b; boundary_fresh = true;
     };
-    int n_chunks = 0, n_launches = 0;
+    uint64_t signature = c->commit_serial * 0x9E3779B97F4A7C15ull;
+    for (uint64_t v : {(uint64_t)res_h, (uint64_t)res_v, (uint64_t)spp, (uint64_t)max_depth, (uint64_t)n_pix_total, (uint64_t)c->chunk_samples, (uint64_t)(corner ? 1 : 0)})
+        signature = (signature ^ v) * 0x100000001B3ull;
+    int n_chunks = 0, n_launches = 0, levels_launched = 0;
     // The whole frame is classified once; the chunks then take consecutive windows of the frame's ACTIVE pixel list, so a sparse
     // frame is one chunk of real work and launches that find their window empty return at once.
     if (classify) {
@@ -824,15 +832,19 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         if (classify) { gen.counts = &fc->counts; gen.block_map = c->d_pos_block.as<uint32_t>(); }   // pix_base = job.id_base: the window's start in the active list
         timed(kStagePrimary, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], c->d_acc.as<double>(), n_samples, max_depth, fc); });
         ++n_launches;
-        for (int b = 1; b <= last_bounce; ++b) {
-            timed(kStageClosest, [&] { ftk::launch_closest(Lc, c->dev_scene, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), b, (uint32_t)c->tail_rays, fc); });
-            timed(kStageShade, [&] { ftk::launch_shade(Ls, c->dev_scene, gen, rb[b & 1], hb, c->d_hit_list.as<uint32_t>(), rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, fc); });
-            n_launches += 2;
-        }
-        if (last_bounce >= 1 && c->tail_rays > 0) {
-            timed(kStageShade, [&] { ftk::launch_tail(Lt, c->dev_scene, gen, rb[0], rb[1], c->d_acc.as<double>(), n_samples, max_depth, (uint32_t)c->tail_rays, fc); });
-            ++n_launches;
-        }
+        // Bounces >= 1: one k_bounce per level of the reflection tree, as many as the previous frame of this signature had (+ 1).
+        // With "timing" = 1 the whole region is one bracket (kind shade): a bracket per launch costs more than a small level does.
+        const bool hinted = c->level_hint && c->staged_hint >= 0 && c->staged_signature == signature;
+        const int n_levels = hinted ? std::min(last_bounce, c->staged_hint + 1) : last_bounce;
+        levels_launched = n_levels;
+        auto bounces = [&](auto&& stage) {
+            for (int b = 1; b <= n_levels; ++b) {
+                stage(kStageShade, [&] { ftk::launch_bounce(Lb, c->dev_scene, gen, rb[b & 1], rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, b == n_levels && n_levels < last_bounce, fc); });
+                ++n_launches;
+            }
+        };
+        if (timing >= 2) bounces(timed);
+        else if (n_levels >= 1) timed(kStageShade, [&] { bounces([](int, auto&& fn) { fn(); }); });
         if (corner) timed(kStageResolve, [&] { ftk::launch_resolve_corner(Lg, c->d_acc.as<double>(), n_samples, job.w, job.h, c->d_out_index.as<uint32_t>() + job.out_base, out_rgb, out_rgba); });
         else {
             ftk::ResolveArgs ra{c->d_acc.as<double>(), n_samples, classify ? &fc->counts : nullptr, job.id_base, n_pix, spp,
@@ -847,6 +859,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     FT_HIP(c, hipGetLastError());
     if (!F.h_tail) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_tail), sizeof(FrameTail), hipHostMallocDefault));
     FT_HIP(c, hipMemcpyAsync(F.h_tail, &fc->stats[0], sizeof(FrameTail), hipMemcpyDeviceToHost, c->stream));   // rides the frame's one wait
+    if (!F.h_rays) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_rays), sizeof(fc->cc.n_rays), hipHostMallocDefault));
+    FT_HIP(c, hipMemcpyAsync(F.h_rays, &fc->cc.n_rays[0], sizeof(fc->cc.n_rays), hipMemcpyDeviceToHost, c->stream));
+    F.signature = signature; F.levels_launched = levels_launched; F.last_bounce = last_bounce;
     F.done = next_event(F);
     if (F.done) FT_HIP(c, hipEventRecord(F.done, c->stream));
     F.ev0 = ev0; F.ev1 = ev1; F.pending = true; F.wall0 = wall0; F.timing = timing;
@@ -871,10 +886,16 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
     for (int k = 0; k < ftk::kStatStripes; ++k) {
         const ftk::RenderCounters& s = F.h_tail->stats[k];
         hrc.rays_shadow += s.rays_shadow; hrc.rays_reflect += s.rays_reflect; hrc.hits_primary += s.hits_primary; hrc.csg_overflow += s.csg_overflow;
-        hrc.ref_equiv += s.ref_equiv; hrc.hits_total += s.hits_total; hrc.tail_in += s.tail_in; hrc.tail_rays += s.tail_rays; hrc.tail_hits += s.tail_hits;
+        hrc.ref_equiv += s.ref_equiv; hrc.hits_total += s.hits_total;
         hrc.pixels_culled += s.pixels_culled; hrc.rays_shadow_primary += s.rays_shadow_primary; hrc.rays_reflect_primary += s.rays_reflect_primary;
     }
     const bool classify_failed = F.h_tail->classify_error != 0;
+    // How deep this frame's rays went: the next frame of the same signature launches that many levels + 1 (a level that followed its
+    // rays in registers does not say how deep they went: then the hint keeps every level it launched).
+    int deepest = 0;
+    while (deepest + 1 <= ftk::kMaxBounce && F.h_rays[deepest + 1] > 0) ++deepest;
+    if (F.levels_launched < F.last_bounce && deepest >= F.levels_launched) deepest = F.last_bounce;   // the followed level had rays: look again with every level next time
+    c->staged_hint = deepest; c->staged_signature = F.signature;
     const int timing = F.timing; const int32_t spp = F.spp; const int64_t n_pix_total = F.n_pix_total; const bool classify = F.classify;
     hipEvent_t ev0 = F.ev0, ev1 = F.ev1;
     double bracketed = 0.0, traced = 0.0;
@@ -903,20 +924,17 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
             // reflection rays spawned by k_primary / in all, H hits of the staged bounces; k_tail's rays and hits never become records:
             // Ti rays were handed to it (written once, read once), Tr spawned and Th shaded inside it.
             const uint64_t P = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, stats->rays_primary_culled);
-            const uint64_t Ti = hrc.tail_in, Tr = hrc.tail_rays, Th = hrc.tail_hits, RR = hrc.rays_reflect, Rp = hrc.rays_reflect_primary;
-            const uint64_t Rstaged = RR - std::min(RR, Ti + Tr);                                  // rays k_closest read (bounce >= 1, not handed to the tail)
-            const uint64_t Hs = hrc.hits_total - std::min(hrc.hits_total, hrc.hits_primary + Th);  // hits k_shade shaded
-            const uint64_t Rs = RR - std::min(RR, Rp + Tr);                                        // rays k_shade spawned
+            const uint64_t RR = hrc.rays_reflect, Rp = hrc.rays_reflect_primary;
+            const uint64_t Hb = hrc.hits_total - std::min(hrc.hits_total, hrc.hits_primary);     // hits shaded by k_bounce
             stats->hits_total = hrc.hits_total;
-            stats->rays_tail = Ti + Tr;
+            stats->rays_tail = 0;
             stats->algorithmic_bytes_primary = P * (ftk::kPixelIdBytes + ftk::kAccBytes) + Rp * ftk::kRayRecBytes;
-            stats->algorithmic_bytes_closest = Rstaged * 48 + Hs * (ftk::kHitRecBytes + ftk::kListBytes);
-            stats->algorithmic_bytes_shade = Hs * (ftk::kHitRecBytes + ftk::kListBytes + 48 + ftk::kRayRecBytes + 2 * ftk::kAccBytes) + Rs * ftk::kRayRecBytes;
+            stats->algorithmic_bytes_closest = 0;
+            stats->algorithmic_bytes_shade = RR * ftk::kRayRecBytes + Hb * 2 * ftk::kAccBytes + (RR - std::min(RR, Rp)) * ftk::kRayRecBytes;   // k_bounce: rays in, colours read-modify-written, rays out
             const uint64_t out_px = F.format == 1 ? 4 : 24, blocks = (uint64_t)n_pix_total / 64;
-            stats->algorithmic_bytes = stats->algorithmic_bytes_primary + stats->algorithmic_bytes_closest + stats->algorithmic_bytes_shade +
-                                       Ti * ftk::kRayRecBytes + Th * 2 * ftk::kAccBytes +                              // + k_tail
+            stats->algorithmic_bytes = stats->algorithmic_bytes_primary + stats->algorithmic_bytes_shade +
                                        P * ftk::kAccBytes + out_px * (uint64_t)n_pix_total + 4 * (uint64_t)n_pix_total +  // + k_resolve: samples in, pixels out, pixel ids
-                                       (classify ? blocks * 16 + (P / (uint64_t)spp) * 2 * ftk::kPixelIdBytes : 0ull);    // + k_classify: two ids in, two words out per block; the list
+                                       (classify ? blocks * 16 : 0ull);                                                 // + k_classify: two ids in, two words out per block
         }
         stats->n_launches = F.n_launches; stats->n_chunks = F.n_chunks;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - F.wall0).count();
@@ -1050,9 +1068,9 @@ static int32_t debug_blocked(ft_context* c, const double* origins, const double*
     return FT_OK;
 }
 
-// getColourForRay (Shading.fs:131-139) for explicit rays through the device path: the rays enter the path kernel (k_tail) as bounce 0
-// with weight 1, so closest hit, shadow queries, shaders and up to max_depth reflection bounces run exactly as they do for a frame's
-// samples.  Streams of soft lights are keyed with seed 0 and sample = ray index.
+// getColourForRay (Shading.fs:131-139) for explicit rays through the device path: the rays enter k_bounce as level 0 with weight 1
+// and are followed to their end, so closest hit, shadow queries, shaders and up to max_depth reflection bounces run exactly as they
+// do for a frame's samples.  Streams of soft lights are keyed with seed 0 and sample = ray index.
 static int32_t debug_colour(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t max_depth, double* rgb);
 int32_t ft_debug_colour(ft_context* c, const double* origins, const double* dirs, int64_t n, int32_t max_depth, double* rgb) {
     if (!c) return FT_ERR_INVALID;
@@ -1088,10 +1106,10 @@ static int32_t debug_colour(ft_context* c, const double* origins, const double* 
     for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;
     if (!c->flat.meshes.empty()) variant |= 4;
-    ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_tail(lds, variant), lds, variant};
+    ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_bounce(lds, variant), lds, variant};
     ftk::Primary gen{};
     gen.pixel_ids = nullptr; gen.pix_base = 0; gen.n_pix = n_rays; gen.spp = 1; gen.inv_n_pix = 1.0 / (double)n_rays; gen.seed = 0ull; gen.counts = nullptr; gen.block_map = nullptr;
-    ftk::launch_tail(Lt, c->dev_scene, gen, rb0, rb1, c->d_acc.as<double>(), n_rays, max_depth, n_rays + 1u, fc, 0);
+    ftk::launch_bounce(Lt, c->dev_scene, gen, rb0, rb1, c->d_acc.as<double>(), n_rays, 0, max_depth, true, fc);   // level 0, followed to the end
     FT_HIP(c, hipGetLastError());
     std::vector<double> planes(3 * N);
     FT_HIP(c, hipMemcpyAsync(planes.data(), c->d_acc.p, 3 * N * 8, hipMemcpyDeviceToHost, c->stream));

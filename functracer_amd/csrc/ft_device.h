@@ -37,29 +37,27 @@ struct DevScene {
     int32_t shadow_rays_per_hit;   // sum over lights of the shadow rays the reference casts per hit
     int32_t n_items, n_cull_rows;  // n_cull_rows < 0: pre-test disabled
     int32_t csg_rows, lane_fold;   // LDS rows per hit-list column and lanes folded together (see HitList): csg_cap <= csg_rows * lane_fold
+    int32_t n_simd;                // SIMDs of the device (CUs x 4): how far few rays are spread (batch_lanes_for)
     int32_t coherent_waves;        // 1 (default): bounce-0 wavefronts use the bundle paths (cone cull, packet traversal); 0: every wave is treated as incoherent (diagnostic)   // sum over lights of the shadow rays the reference casts per hit
 };
 
-// Ray wavefront buffer, struct-of-arrays so a wave's 64 records are 512 contiguous bytes per field.
-// sizeof(RayRec) = 7*8 + 4 = 60 bytes; HitRec = 8 + 4 + 4 = 16 bytes (roofline).
+// Ray wavefront buffer, struct-of-arrays so a wave's 64 records are 512 contiguous bytes per field: 7 doubles + the sample slot =
+// 60 bytes per reflection ray (roofline).  Hits never become records: a level's closest hits are shaded in the same kernel.
 struct RayBuf { double *ox, *oy, *oz, *dx, *dy, *dz, *w; uint32_t* slot; };
-struct HitBuf { double* t; uint32_t* id0; uint32_t* id1; };
-constexpr uint64_t kRayRecBytes = 60, kHitRecBytes = 16;
-// Bytes a launch has to move per unit, by construction of the pipeline (roofline): a primary ray costs a 4-byte
-// pixel id read and a 1-byte flag write (it is regenerated, never stored); a reflection ray a 60-byte record written once and
-// read in k_closest (48 B: origin + direction) and twice in k_shade; a hit a 16-byte record + 4-byte list entry, written once,
-// read once; an accumulator 24 B stored (bounce 0) or read-modify-written (later bounces); a pixel 24 B out.
-constexpr uint64_t kPixelIdBytes = 4, kTouchedBytes = 1, kListBytes = 4, kAccBytes = 24;
+constexpr uint64_t kRayRecBytes = 60;
+// Bytes a launch has to move per unit, by construction of the pipeline (roofline): a primary ray costs a 4-byte pixel id
+// read and its sample's 24-byte colour stored (it is generated, never stored); a reflection ray a 60-byte record written once and read
+// once; a hit of a later bounce a 48-byte read-modify-write of its sample's colour; a pixel 24 B (4 B as RGBA8) out.
+constexpr uint64_t kPixelIdBytes = 4, kAccBytes = 24;
 
 // Length of the frame's active pixel list (k_classify), in device memory: the later stages size themselves from it.
 struct PixCount { uint32_t n_pix, pad[3]; };
 // Per-chunk device counters (zeroed before every chunk).
 struct ChunkCounters {
     uint32_t n_rays[kMaxBounce + 2];   // rays queued for bounce k
-    uint32_t n_hits[kMaxBounce + 2];   // compacted lit/unlit hit count of bounce k
-    // Work cursors: kWorkGroups independent counters per kernel and bounce, one 64-byte line each (see ft_kernels.hip).
+    uint32_t pad[14];
+    // Work cursors: kWorkGroups independent counters per bounce, one 64-byte line each (see ft_kernels.hip).
     uint32_t work_trace[kMaxBounce + 2][kWorkGroups * 16];
-    uint32_t work_shade[kMaxBounce + 2][kWorkGroups * 16];
 };
 // Per-render device statistics.  Every wave adds what it counted to one of kStatStripes copies (its wave index mod 64), one
 // no-return atomic per non-zero counter at the end of a launch; the host sums the stripes when it retires the frame.
@@ -67,7 +65,7 @@ struct RenderCounters {
     unsigned long long rays_shadow, rays_reflect, hits_primary, csg_overflow;
     double ref_equiv;
     unsigned long long hits_total;      // hits shaded over all bounces
-    unsigned long long tail_in, tail_rays, tail_hits;   // k_tail: rays handed over, reflection rays it spawned, hits it shaded
+    unsigned long long unused[3];
     unsigned long long pixels_culled;                   // k_classify: pixels whose every primary ray provably misses everything
     unsigned long long rays_shadow_primary, rays_reflect_primary;   // the k_primary share of rays_shadow / rays_reflect
     unsigned long long pad[4];                          // 128 bytes: one stripe per pair of cache lines
@@ -117,16 +115,11 @@ struct Primary {
 // one colour per sample stored into acc (Colour.Zero for a miss).
 void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint32_t acc_stride, int max_depth, FrameCounters* fc);
 int occupancy_blocks_primary(size_t lds_bytes, int variant);
-// Bounce k >= 1, staged: closest hit of every reflection ray of bounce k; compacts the indices of rays that hit into hit_list.
-void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, uint32_t tail_threshold, FrameCounters* fc);
-// Shading + shadow rays + accumulation for the compacted hits of bounce k >= 1; emits bounce k+1 rays.
-void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next,
-                  double* acc, uint32_t acc_stride, int bounce, int max_depth, FrameCounters* fc);
-// Tail of the bounce loop (k_tail): once a bounce has fewer than `threshold` rays the per-bounce stages stand down and this one
-// launch follows every remaining path to its end inside registers.
-void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
-                 int max_depth, uint32_t threshold, FrameCounters* fc, int first_bounce = 1);
-int occupancy_blocks_tail(size_t lds_bytes, int variant);
+// One level of the reflection tree (bounce k >= 1) fused (k_bounce): closest hit, shadow queries, shaders and accumulation for every
+// ray of rays (n = fc->cc.n_rays[bounce]); the level's reflection rays are compacted into `next`, or, with `follow`, followed to their
+// end inside the launch (the last level the host launches).  A launch that finds no rays returns at once.
+void launch_bounce(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, RayBuf next, double* acc, uint32_t acc_stride, int bounce, int max_depth, bool follow, FrameCounters* fc);
+int occupancy_blocks_bounce(size_t lds_bytes, int variant);
 // Pixel-block classification + compaction in one kernel.  One LANE per 64-pixel block (an 8x8 tile of the pixel list): the block's
 // ray bundle - all samples of its pixels - is bounded by a cone through its outermost jittered corners and tested against every
 // top-level item (bare meshes also against their coarse boxes).  Blocks nothing can be hit from get block_pos = -1 (k_resolve writes

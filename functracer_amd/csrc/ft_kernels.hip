@@ -5,10 +5,9 @@
 // per chunk of samples of the active list:
 //   k_primary   bounce 0, fused: primary rays generated in registers (Image.fs:83-89, 100-110), closest hit (Scene.fs:112-118 over
 //               the flattened Scene.intersect, Scene.fs:67-104), shadow rays + Phong + reflection spawn (Shading.fs:24-139)
-//   k_closest / k_shade   the same two halves as separate stages for the reflection rays of bounce k >= 1: rays and hit records
-//               live in wavefront buffers in HBM, rays that terminate are dropped by wave-ballot / prefix-sum compaction, so every
-//               lane of the next stage is live
-//   k_tail      the same, path by path, for the few rays of the late bounces (one launch instead of two per bounce)
+//   k_bounce    one launch per level of the reflection tree (bounce k >= 1), fused the same way: the rays live in a ping-pong
+//               wavefront buffer in HBM, the ones that terminate are dropped by wave-ballot / prefix-sum compaction when the next
+//               level is spawned, so every lane of a level is live
 //   k_resolve   per-pixel mean (Image.fs:112-116), Colour.Zero for the blocks k_classify finished, FP64 and / or RGBA8 (Image.fs:36)
 // All tracing kernels are persistent grids whose waves pull 64-ray batches from 64 interleaved cursors.
 //
@@ -92,7 +91,7 @@ struct Scene {
     const float* coarse_boxes;   // lane k reads box k
     cdp cull_rows;
     cup item_pc;
-    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold;
+    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold, n_simd;
 };
 static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
 template <class DS> FT_DEV Scene scene_view(const DS& g) {
@@ -104,7 +103,7 @@ template <class DS> FT_DEV Scene scene_view(const DS& g) {
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig); s.wide = to_const_as(g.wide); s.mesh_wide = to_const_as(g.mesh_wide);
     s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.coarse_boxes = g.coarse_boxes; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
-    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap; s.csg_rows = g.csg_rows; s.lane_fold = g.lane_fold;
+    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap; s.csg_rows = g.csg_rows; s.lane_fold = g.lane_fold; s.n_simd = g.n_simd;
     return s;
 }
 struct MaterialV { double colour[3]; double roughness, reflectance, shineyness; uint32_t apply_lighting; int32_t texture; uint32_t hue_rot; };
@@ -663,6 +662,7 @@ FT_DEV float wave_min(float v) {                                    // all 64 la
     const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return fminf(fminf(a, b), fminf(c, d));
 }
+constexpr int kSparseLanes = 8;                                     // at most this many live rays: exact_cull tests lane = item
 struct ItemMask { unsigned long long lo, hi; bool valid; };   // bit k: top-level item k may be hit by some ray of the wave (items >= 128: not covered)
 // A bundle of rays bounded by a cone: apex c (origins within rho of it), unit axis a, half-angle given by cos_t (rounded down) /
 // sin_t (rounded up); par_rows = face directions some ray of the bundle may be nearly parallel to.
@@ -731,11 +731,11 @@ FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows});
 }
 
-// Exact skip test of one top-level item for this lane's ray (see OP_CULL).
-FT_DEV bool item_missed(const Scene& S, uint32_t item, const Ray& r) {
-    cdp C = S.culls + 24ull * item;
-    const double ocx = r.ox - C[0], ocy = r.oy - C[1], ocz = r.oz - C[2];
-    const double dd = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz), b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz), cc = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
+// Exact skip test of one top-level item (cull record C: centre, radius^2, number of face directions, the directions) for one ray.
+template <class P>
+FT_DEV bool item_missed_by(P C, double ox, double oy, double oz, double dx, double dy, double dz) {
+    const double ocx = ox - C[0], ocy = oy - C[1], ocz = oz - C[2];
+    const double dd = dot3(dx, dy, dz, dx, dy, dz), b = dot3(ocx, ocy, ocz, dx, dy, dz), cc = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
     // (1) the squared distance from the centre to the ray's LINE exceeds the inflated radius: no hit at any t;
     // (2) the origin is outside the sphere and moving away: every hit of the item has t < 0, which neither
     //     closest (Scene.fs:115) nor lightIsBocked (Scene.fs:121) ever uses (CSG state inside the item is moot).
@@ -745,8 +745,15 @@ FT_DEV bool item_missed(const Scene& S, uint32_t item, const Ray& r) {
     if (cc > C[3] && b > 0.0) miss = true;
     const int n_rows = (int)C[4];
     for (int k = 0; k < n_rows; ++k)                               // near-parallel to a plane-derived face: Plane.fs:13-16 may hit at the origin
-        if (fabs(dot3(C[5 + 3 * k], C[6 + 3 * k], C[7 + 3 * k], r.dx, r.dy, r.dz)) < 2.0 * kEps) miss = false;
+        if (fabs(dot3(C[5 + 3 * k], C[6 + 3 * k], C[7 + 3 * k], dx, dy, dz)) < 2.0 * kEps) miss = false;
     return miss;
+}
+// ... for this lane's ray, the record through scalar loads (see OP_CULL).
+FT_DEV bool item_missed(const Scene& S, uint32_t item, const Ray& r) { return item_missed_by(S.culls + 24ull * item, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz); }
+FT_DEV double readlane_f64(double v, int lane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 // The same test for every item up front (incoherent waves): the loads of consecutive records do not depend on each other,
 // unlike the walk through the program from one OP_CULL to the next, and the wave then visits only what some lane needs.
@@ -754,6 +761,26 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
     ItemMask M{0ull, 0ull, false};
     const int n = S.n_items < 128 ? S.n_items : 128;
     if (S.n_items < 3) return ItemMask{~0ull, ~0ull, false};
+    const unsigned long long lm = __ballot(live);
+    if (__popcll(lm) <= kSparseLanes) {
+        // Few live rays (the late bounces: a handful of lanes per wave): the roles swap.  Lane k holds ITEM k's record and the live
+        // rays are broadcast one at a time, so the wave pays a few dozen instructions per ray instead of a scalar-load round trip
+        // and a test per item (measured on hollow-sphere x1: the tail's eight bounces are a chain of such walks).
+        for (int pass = 0; pass * 64 < n; ++pass) {
+            const int item = pass * 64 + (int)lane_id();
+            cdp C = S.culls + 24ull * (uint32_t)(item < n ? item : 0);   // per-lane record: vector loads (the address differs per lane)
+            bool need = false;
+            unsigned long long todo = lm;
+            while (todo) {
+                const int src = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
+                if (!item_missed_by(C, readlane_f64(r.ox, src), readlane_f64(r.oy, src), readlane_f64(r.oz, src), readlane_f64(r.dx, src), readlane_f64(r.dy, src), readlane_f64(r.dz, src))) need = true;
+            }
+            const unsigned long long km = __ballot(need && item < n);
+            if (pass == 0) M.lo = km; else M.hi = km;
+        }
+        M.valid = true;
+        return M;
+    }
     for (int k = 0; k < n; ++k) {
         const bool need = live && !item_missed(S, (uint32_t)k, r);
         if (__any(need)) { if (k < 64) M.lo |= 1ull << k; else M.hi |= 1ull << (k - 64); }
@@ -765,7 +792,7 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
 // ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
 // MESH = false compiles the triangle / BSP / BVH code out: scenes without meshes then run kernels with
-// markedly fewer registers (k_closest 123 -> 92 VGPRs, 4 -> 5 waves per SIMD).
+// markedly fewer registers.
 template <bool ANY, bool MESH>
 FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow, bool coherent = false) {
     HitList L;
@@ -1035,12 +1062,15 @@ struct BatchCursor {
 };
 //
 // Rays per batch: a wave's cost grows with the number of DISTINCT scene items its rays touch, so when a launch has
-// fewer rays than the grid has lanes (late bounces: a few hundred incoherent reflection rays), the rays are spread
-// thinly — 32, 16, ... 1 per wave — over the otherwise idle waves instead of packing 64 unrelated rays into one.
-FT_DEV uint32_t batch_lanes_for(uint32_t n, int lane_fold) {
-    const uint32_t waves = gridDim.x * (kBlock / 64);
+// few rays (late bounces: a few hundred incoherent reflection rays), they are spread thinly — 32, 16, ... 1 per batch —
+// over the otherwise idle SIMDs instead of packing 64 unrelated rays into one wave.
+FT_DEV uint32_t batch_lanes_for(uint32_t n, int lane_fold, int n_simd) {
+    // A batch costs a fixed part (the walk through the scene program: ~17 us of issue time on an otherwise idle SIMD for one
+    // incoherent ray) plus ~1 us per further ray, and the SIMD, not the wave, is what that time is spent on.  So the rays are spread
+    // only as far as it takes to give every SIMD one batch: the narrowest batches that still fit in one round.  (Spreading until
+    // every WAVE had a batch made a level of 15 K rays 7.5 K two-ray batches: 119 us instead of ~35.)
     uint32_t b = 64u / (uint32_t)lane_fold;                         // folded lanes lend their LDS columns to the live ones (HitList)
-    while (b > 1u && n < b * waves) b >>= 1;
+    while (b > 1u && n <= (b >> 1) * (uint32_t)n_simd) b >>= 1;
     return b;
 }
 
@@ -1114,7 +1144,7 @@ FT_DEV unsigned long long sample_id(PrimaryArg g, const Pix& px, uint32_t slot) 
     return (unsigned long long)pid * (unsigned long long)g->spp + s;
 }
 
-// Primary rays are never stored: bounce 0 of k_closest / k_shade regenerates them from the sample index
+// Primary rays are never stored: k_primary generates them from the sample index
 // (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
 // 64 pixels of one 8x8 block for one jitter offset).
 FT_DEV uint32_t primary_pixel(PrimaryArg g, const Pix& px, uint32_t i) {   // the one memory access a primary ray needs
@@ -1143,78 +1173,7 @@ FT_DEV Ray primary_ray_from(PrimaryArg g, const Pix& count, uint32_t i, uint32_t
     return r;
 }
 
-struct ClosestArgs {
-    DevScene S; RayBuf rays; HitBuf hits;
-    uint32_t* hit_list; FrameCounters* fc; int32_t bounce; uint32_t tail_threshold;
-};
-
-// Resident blocks per CU the compiler must leave room for (measured: 3, 5, 6 are slower - spills or too few waves).
-#ifndef FT_CLOSEST_BLOCKS
-#define FT_CLOSEST_BLOCKS 4
-#endif
-// Closest hit of the reflection rays of bounce k >= 1 (bounce 0 runs in k_primary); the rays that hit are compacted into hit_list.
-template <bool MESH>
-__global__ __launch_bounds__(kBlock, FT_CLOSEST_BLOCKS) void k_closest(ClosestArgs) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const FT_CONST ClosestArgs* K = kernel_args<ClosestArgs>();
-    const Scene S = scene_view(K->S);
-    const int bounce = K->bounce;
-    ChunkCounters* cc = &K->fc->cc;
-    const uint32_t n = cc->n_rays[bounce];
-    if (n < K->tail_threshold) return;                             // few rays left: k_tail follows them to the end (nothing is spawned after this bounce)
-    const uint32_t B = batch_lanes_for(n, S.lane_fold);
-    const uint32_t n_batches = (n + B - 1) / B;
-    unsigned long long n_ovf_wave = 0;
-    // Compaction of the rays that hit (wave ballot + prefix sum): hit masks of up to 48 batches are parked in the
-    // lanes of three VGPRs (lane k = k-th pending batch) and flushed with ONE reservation on the hit counter.
-    uint32_t mask_lo = 0, mask_hi = 0, base_of = 0, pending = 0, pending_hits = 0;
-    auto flush = [&]() {
-        if (pending_hits) {
-            const FT_CONST ClosestArgs* Kf = fresh(K);
-            uint32_t* hit_list = Kf->hit_list;
-            uint32_t dst = 0;
-            if (lane_id() == 0) dst = atomicAdd(&Kf->fc->cc.n_hits[bounce], pending_hits);
-            dst = __builtin_amdgcn_readfirstlane(dst);
-            for (uint32_t k = 0; k < pending; ++k) {
-                const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_lo, (int)k) |
-                                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mask_hi, (int)k) << 32);
-                const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)base_of, (int)k);
-                if ((m >> lane_id()) & 1ull) hit_list[dst + lanes_below(m)] = bs + lane_id();
-                dst += (uint32_t)__popcll(m);
-            }
-        }
-        pending = 0; pending_hits = 0;
-    };
-    BatchCursor cursor(&cc->work_trace[bounce][0]);
-    uint32_t bi = cursor.grab(), bi_next = cursor.grab();           // two deep: the index after next is in flight while this batch runs
-    for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
-        const uint32_t base = bi * B;
-        const uint32_t i = base + lane_id();
-        Query<false> q;
-        q.active = i < n && lane_id() < B; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
-        Ray r{0, 0, 0, 0, 0, 0};
-        if (q.active) {
-            const FT_CONST RayBuf& rays = fresh(K)->rays;           // ray buffers: loaded here, dead before the trace
-            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
-            r.ox = r.ox + 0.0001 * r.dx; r.oy = r.oy + 0.0001 * r.dy; r.oz = r.oz + 0.0001 * r.dz;   // slightOffset (Shading.fs:129)
-        }
-        bool overflow;
-        trace<false, MESH>(S, r, q, lds, overflow, false);
-        const bool hit = q.active && q.id0 != ID_MISS;
-        if (hit) { const FT_CONST HitBuf& hits = fresh(K)->hits; hits.t[i] = q.best_t; hits.id0[i] = q.id0; hits.id1[i] = q.id1; }   // only rays that hit are ever looked at again
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-            if (lane_id() == pending) { mask_lo = (uint32_t)m; mask_hi = (uint32_t)(m >> 32); base_of = base; }
-            ++pending; pending_hits += (uint32_t)__popcll(m);
-            if (pending == 48u) flush();
-        }
-        n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && q.active));
-    }
-    flush();
-    wave_add(&my_stats(fresh(K)->fc)->csg_overflow, n_ovf_wave);
-}
-
-// k_shade variants: FANCY = Oren-Nayar and grid textures compiled in (libm-heavy code: acos, tan, atan2 ...),
+// Kernel variants: FANCY = Oren-Nayar and grid textures compiled in (libm-heavy code: acos, tan, atan2 ...),
 // SOFT = softdirectional lights, MESH = triangle meshes.  Scenes that lack a feature run a leaner kernel.
 //
 // Two passes over the lights keep the live state across the shadow traces small (p, n and a few words instead
@@ -1339,104 +1298,6 @@ FT_DEV void shade_lights(const Scene& S, const Surface& sf, const MaterialV& mat
     }
 }
 
-struct ShadeArgs {
-    DevScene S; Primary gen; RayBuf rays; HitBuf hits; RayBuf next;
-    const uint32_t* hit_list; double* acc; FrameCounters* fc;
-    uint32_t acc_stride; int32_t bounce, max_depth;
-};
-
-// Shading of the compacted hits of bounce k >= 1 (bounce 0 runs in k_primary).
-template <bool FANCY, bool SOFT, bool MESH>
-#ifndef FT_SHADE_BLOCKS
-#define FT_SHADE_BLOCKS 4
-#endif
-__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(ShadeArgs) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const FT_CONST ShadeArgs* K = kernel_args<ShadeArgs>();
-    const Scene S = scene_view(K->S);
-    const int bounce = K->bounce;
-    ChunkCounters* cc = &K->fc->cc;
-    const uint32_t n = cc->n_hits[bounce];
-    const Pix px = pix_count(&K->gen);                              // once per launch: the count sits two dependent loads away
-    const int n_lights = S.n_lights;                               // <= 16 (checked at commit)
-    unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
-    const uint32_t B = batch_lanes_for(n, S.lane_fold);
-    const uint32_t n_batches = (n + B - 1) / B;
-    BatchCursor cursor(&cc->work_shade[bounce][0]);
-    for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
-        const uint32_t base = bi * B;
-        const uint32_t j = base + lane_id();
-        const bool active = j < n && lane_id() < B;
-        // ---------------- pass 1: surface point + visibility of every light -------------------------------
-        Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
-        bool lit = false;
-        unsigned long long sample = 0ull;
-        if (active) {
-            const FT_CONST ShadeArgs* Kb = fresh(K);                // buffers: loaded here, dead before the shadow traces
-            const uint32_t i = Kb->hit_list[j];
-            const FT_CONST RayBuf& rays = Kb->rays;
-            const Ray r{rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]};
-            const FT_CONST HitBuf& hits = Kb->hits;
-            // the geometry saw the offset ray (Shading.fs:135); the view ray keeps the original origin (Shading.fs:137)
-            const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};
-            sf = surface_at<FANCY>(S, ro, hits.t[i], hits.id0[i], hits.id1[i]);
-            lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
-            if (SOFT) sample = sample_id(&Kb->gen, px, rays.slot[i]);
-        }
-        unsigned long long vis_lo, vis_hi;                         // byte l = occluded shadow samples of light l
-        light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, bounce, false, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
-        // ---------------- pass 2: the shaders (Shading.fs:50-107) with everything reloaded ------------------
-        Ray r{0, 0, 0, 0, 0, 0};
-        double w = 0.0; uint32_t slot = 0;
-        const FT_CONST ShadeArgs* K2 = fresh(K);
-        if (active) {
-            const uint32_t i = K2->hit_list[j];
-            const FT_CONST RayBuf& rays = K2->rays;
-            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i];
-        }
-        MaterialV mat = material_at(S, sf.material);               // per-lane gather (64 B records, L1/L2 resident)
-        if (FANCY) { if (active && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }   // Ray.textureDiffuse (Ray.fs:57-59)
-        double cr, cg, cb;
-        shade_lights<FANCY, SOFT>(S, sf, mat, r, active, lit, vis_lo, vis_hi, cr, cg, cb);
-        if (active) {                                              // one ray per sample per bounce: no write conflicts, fixed order
-            double* acc = K2->acc; const uint32_t acc_stride = K2->acc_stride;
-            acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
-        }
-        // reflectionShader (Shading.fs:89-98): every one of the L fragments adds reflectance * colour(reflected ray);
-        // those L sub-traces are identical (deterministic lights, or streams keyed without the parent light), so one
-        // ray carries weight L * reflectance.
-        const bool spawn = lit && mat.reflectance > 0.0 && bounce < K2->max_depth;
-        const unsigned long long m = __ballot(spawn);
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        uint32_t dst = 0;
-        if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->fc->cc.n_rays[bounce + 1], cnt);
-        dst = __builtin_amdgcn_readfirstlane(dst);
-        if (spawn) {
-            const uint32_t o = dst + lanes_below(m);
-            const FT_CONST RayBuf& next = K2->next;
-            const double k2 = 2.0 * dot3(r.dx, r.dy, r.dz, sf.n.x, sf.n.y, sf.n.z);
-            next.ox[o] = sf.p.x; next.oy[o] = sf.p.y; next.oz[o] = sf.p.z;
-            next.dx[o] = r.dx - k2 * sf.n.x; next.dy[o] = r.dy - k2 * sf.n.y; next.dz[o] = r.dz - k2 * sf.n.z;
-            next.w[o] = w * (mat.reflectance * (double)n_lights);
-            next.slot[o] = slot;
-        }
-        n_refl_wave += cnt;
-        n_hit_wave += (unsigned long long)__popcll(__ballot(active));
-    }
-    RenderCounters* mine = my_stats(fresh(K)->fc);
-    wave_add(&mine->rays_shadow, n_shadow_wave);
-    wave_add(&mine->rays_reflect, n_refl_wave);
-    wave_add(&mine->hits_total, n_hit_wave);
-    wave_add(&mine->csg_overflow, n_ovf_wave);
-    // what the F# recursion would trace: at depth k every ray exists L^k times; each hit casts its shadow rays
-    // and each reflective hit L reflection rays (Shading.fs:109-139).
-    if (n_hit_wave || n_refl_wave) {
-        double mult = 1.0;                                          // L^bounce by multiplication: exact, pow is not for L = 3
-        for (int k = 0; k < bounce; ++k) mult *= (double)n_lights;
-        wave_add(&mine->ref_equiv, mult * ((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave));
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_primary: bounce 0 as ONE kernel (the north star's fused megakernel, used where the work is coherent).  A wave takes a batch of
 // 64 primary rays - one 8x8 pixel block for one jitter offset - generates them (Image.fs:83-89), finds their closest hits as a
@@ -1444,8 +1305,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_SHADE_BLOCKS) void k_shade(S
 // the hit and the surface still in registers: no hit record, no hit list, no second generation of the ray, and the block's shadow
 // rays stay one tight bundle instead of being compacted with those of other blocks.  Every live lane stores its sample's colour
 // (Colour.Zero for a miss: Scene.fs:116), so the accumulator planes are written in whole lines; reflection rays are spawned into
-// the bounce-1 wavefront buffer exactly as k_shade does.  Same device functions in the same order per sample as the staged
-// kernels, so a frame does not depend on which of the two routes bounce 0 takes.
+// the bounce-1 wavefront buffer for k_bounce.
 struct PrimaryArgs {
     DevScene S; Primary gen; RayBuf next;
     double* acc; FrameCounters* fc;
@@ -1468,7 +1328,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_prima
     const uint32_t n = n_pix * (uint32_t)K->gen.spp;
     const int n_lights = S.n_lights;
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
-    const uint32_t B = batch_lanes_for(n, S.lane_fold);
+    const uint32_t B = batch_lanes_for(n, S.lane_fold, S.n_simd);
     const uint32_t n_batches = (n + B - 1) / B;
     const bool uniform_s = B == 64u && (n_pix & 63u) == 0u;
     const bool coherent = K->S.coherent_waves != 0;
@@ -1480,7 +1340,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_prima
         const uint32_t i = bi * B + lane_id();
         const uint32_t pid = pid_next;
         const bool active = i < n && lane_id() < B;
-        // ---- closest hit (k_closest); the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
+        // ---- closest hit; the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
         Ray ro{0, 0, 0, 0, 0, 0};
         {
             const FT_CONST PrimaryArgs* Kb = fresh(K);              // camera, pixel list: loaded here, dead before the trace
@@ -1499,7 +1359,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_prima
         const unsigned long long hit_mask = __ballot(hit);
         double cr = 0.0, cg = 0.0, cb = 0.0;                        // a sample whose primary ray hits nothing is Colour.Zero
         if (hit_mask) {
-            // ---- shade (k_shade)
+            // ---- shade
             Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
             bool lit = false;
             unsigned long long sample = 0ull;
@@ -1516,7 +1376,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_prima
             const FT_CONST PrimaryArgs* K2 = fresh(K);
             const Ray rv = hit ? primary_ray_from(&K2->gen, px, i, pid, uniform_s) : Ray{0, 0, 0, 0, 0, 0};
             shade_lights<FANCY, SOFT>(S, sf, mat, rv, hit, lit, vis_lo, vis_hi, cr, cg, cb);
-            // reflectionShader (Shading.fs:89-98), see k_shade: one ray of weight L * reflectance stands for the L identical sub-traces
+            // reflectionShader (Shading.fs:89-98), see k_bounce: one ray of weight L * reflectance stands for the L identical sub-traces
             const bool spawn = lit && mat.reflectance > 0.0 && 0 < K2->max_depth;
             const unsigned long long m = __ballot(spawn);
             const uint32_t cnt = (uint32_t)__popcll(m);
@@ -1551,6 +1411,123 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_prima
     wave_add(&mine->csg_overflow, n_ovf_wave);
     // what the F# recursion would trace (Shading.fs:109-139), depth 0
     wave_add(&mine->ref_equiv, (double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bounce: one level of the reflection tree (bounce k >= 1) as one kernel - the same fusion as k_primary, for rays that come out
+// of the wavefront buffer instead of the camera: closest hit, shadow queries, shaders, accumulation into the sample's colour and
+// the spawn of the level's reflection rays, compacted by wave ballot + prefix sum into the other half of the ping-pong buffer, so
+// every lane of the next level is live.  The host launches one k_bounce per level, as many as the previous frame of the same
+// scene had levels with rays, plus one (a launch that finds no rays returns at once; the last one launched FOLLOWS whatever it
+// still spawns to the end in registers, so a frame that goes deeper than its predecessor is complete all the same); round 1 ran a closest / shade pair per large
+// level and one path-following kernel for the rest, whose waves kept dragging a few live lanes through eight levels (measured on
+// hollow-sphere x1: 0.76 of the frame's 1.05 ms).  Few rays are spread thinly over the grid (batch_lanes_for).
+struct BounceArgs {
+    DevScene S; Primary gen; RayBuf rays; RayBuf next;
+    double* acc; FrameCounters* fc;
+    uint32_t acc_stride; int32_t bounce, max_depth;
+    int32_t follow;                                                // the last level launched: rays it spawns are followed to their end in registers, not queued
+};
+#ifndef FT_BOUNCE_BLOCKS
+#define FT_BOUNCE_BLOCKS 4
+#endif
+template <bool FANCY, bool SOFT, bool MESH>
+__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_BOUNCE_BLOCKS) void k_bounce(BounceArgs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const FT_CONST BounceArgs* K = kernel_args<BounceArgs>();
+    const int bounce = K->bounce;
+    ChunkCounters* cc = &K->fc->cc;
+    const uint32_t n = cc->n_rays[bounce];
+    if (n == 0u) return;
+    const Scene S = scene_view(K->S);
+    const Pix px = pix_count(&K->gen);
+    const int n_lights = S.n_lights;
+    const bool follow = K->follow != 0;
+    unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
+    double ref_wave = 0.0;
+    double mult0 = 1.0;                                             // copies of a ray of this level in the F# recursion (Shading.fs:109-139): L^bounce, exactly
+    for (int k = 0; k < bounce; ++k) mult0 *= (double)n_lights;
+    const uint32_t B = batch_lanes_for(n, S.lane_fold, S.n_simd);
+    const uint32_t n_batches = (n + B - 1) / B;
+    BatchCursor cursor(&cc->work_trace[bounce][0]);
+    for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
+        const uint32_t i = bi * B + lane_id();
+        bool alive = i < n && lane_id() < B;
+        Ray r{0, 0, 0, 0, 0, 0};
+        double w = 0.0; uint32_t slot = 0;
+        if (alive) {
+            const FT_CONST RayBuf& rays = fresh(K)->rays;           // buffers: loaded here, dead before the trace
+            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i];
+        }
+        double mult = mult0;
+        for (int depth = bounce;; ++depth, mult *= (double)n_lights) {   // one pass, unless this launch follows its rays to the end
+            // ---- closest hit; the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
+            const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
+            Query<false> q;
+            q.active = alive; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
+            bool overflow;
+            trace<false, MESH>(S, ro, q, lds, overflow, false);
+            n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && alive));
+            const bool hit = alive && q.id0 != ID_MISS;
+            const unsigned long long hit_mask = __ballot(hit);
+            if (hit_mask == 0ull) break;                            // a ray that hits nothing adds Colour.Zero
+            // ---- shade
+            Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
+            bool lit = false;
+            unsigned long long sample = 0ull;
+            if (hit) {
+                sf = surface_at<FANCY>(S, ro, q.best_t, q.id0, q.id1);
+                lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
+                if (SOFT) sample = sample_id(&fresh(K)->gen, px, slot);
+            }
+            unsigned long long vis_lo, vis_hi;
+            light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, depth, false, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
+            MaterialV mat = material_at(S, sf.material);
+            if (FANCY) { if (hit && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
+            double cr, cg, cb;
+            shade_lights<FANCY, SOFT>(S, sf, mat, r, hit, lit, vis_lo, vis_hi, cr, cg, cb);
+            const FT_CONST BounceArgs* K2 = fresh(K);
+            if (hit) {                                              // one ray per sample per level: no write conflicts, fixed order
+                double* acc = K2->acc; const uint32_t acc_stride = K2->acc_stride;
+                acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
+            }
+            // reflectionShader (Shading.fs:89-98): every one of the L fragments adds reflectance * colour(reflected ray); those L sub-traces
+            // are identical (deterministic lights, or streams keyed without the parent light), so one ray carries weight L * reflectance.
+            const bool spawn = lit && mat.reflectance > 0.0 && depth < K2->max_depth;
+            const unsigned long long m = __ballot(spawn);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            n_refl_wave += cnt;
+            n_hit_wave += (unsigned long long)__popcll(hit_mask);
+            ref_wave += mult * ((double)K2->S.shadow_rays_per_hit * (double)__popcll(hit_mask) + (double)n_lights * (double)cnt);
+            const double k2 = 2.0 * dot3(r.dx, r.dy, r.dz, sf.n.x, sf.n.y, sf.n.z);
+            if (!follow) {                                          // the level's reflection rays, compacted into the other buffer
+                uint32_t dst = 0;
+                if (lane_id() == 0 && cnt) dst = atomicAdd(&K2->fc->cc.n_rays[depth + 1], cnt);
+                dst = __builtin_amdgcn_readfirstlane(dst);
+                if (spawn) {
+                    const uint32_t o = dst + lanes_below(m);
+                    const FT_CONST RayBuf& next = K2->next;
+                    next.ox[o] = sf.p.x; next.oy[o] = sf.p.y; next.oz[o] = sf.p.z;
+                    next.dx[o] = r.dx - k2 * sf.n.x; next.dy[o] = r.dy - k2 * sf.n.y; next.dz[o] = r.dz - k2 * sf.n.z;
+                    next.w[o] = w * (mat.reflectance * (double)n_lights);
+                    next.slot[o] = slot;
+                }
+                break;
+            }
+            if (cnt == 0u) break;
+            if (spawn) {                                            // followed in registers: same ray, same weight as the queued one would carry
+                r = {sf.p.x, sf.p.y, sf.p.z, r.dx - k2 * sf.n.x, r.dy - k2 * sf.n.y, r.dz - k2 * sf.n.z};
+                w = w * (mat.reflectance * (double)n_lights);
+            }
+            alive = spawn;
+        }
+    }
+    RenderCounters* mine = my_stats(fresh(K)->fc);
+    wave_add(&mine->rays_shadow, n_shadow_wave);
+    wave_add(&mine->rays_reflect, n_refl_wave);
+    wave_add(&mine->hits_total, n_hit_wave);
+    wave_add(&mine->csg_overflow, n_ovf_wave);
+    wave_add(&mine->ref_equiv, ref_wave);                           // what the F# recursion would trace (Shading.fs:109-139)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1766,106 +1743,6 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify(ClassifyArgs) {
     FT_STAMP(5);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_tail: the end of the bounce loop as one launch.  Late bounces carry few, incoherent rays; run as closest / shade stages
-// each of them costs two launches whose time is the latency of a single batch (~30-100 us: every stage boundary sends the
-// ray and hit records through HBM, across XCDs).  Once a bounce k >= 1 starts with fewer than `threshold` rays, k_closest
-// stands down (so nothing more is spawned) and this kernel takes those rays and follows every path to its end - closest hit,
-// shadow queries, shaders, reflection - with the ray in registers.  Same device functions, same arithmetic and the same
-// accumulation order per sample as the staged bounces, so frames do not depend on where the hand-over happens.
-struct TailArgs {
-    DevScene S; Primary gen; RayBuf rays[2];
-    double* acc; FrameCounters* fc;
-    uint32_t acc_stride; int32_t max_depth; uint32_t threshold;
-    int32_t first_bounce;                                          // 1 in a frame; 0 for ft_debug_colour, whose rays are primary rays (rays[0], n_rays[0])
-};
-
-#ifndef FT_TAIL_BLOCKS
-#define FT_TAIL_BLOCKS 2
-#endif
-template <bool FANCY, bool SOFT, bool MESH>
-__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_TAIL_BLOCKS) void k_tail(TailArgs) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const FT_CONST TailArgs* K = kernel_args<TailArgs>();
-    ChunkCounters* cc = &K->fc->cc;
-    const int max_depth = K->max_depth;
-    int k0 = -1; uint32_t n = 0;
-    for (int k = K->first_bounce; k <= max_depth; ++k) { const uint32_t nk = cc->n_rays[k]; if (nk > 0u && nk < K->threshold) { k0 = k; n = nk; break; } }
-    if (k0 < 0) return;
-    const Pix px = pix_count(&K->gen);
-    const Scene S = scene_view(K->S);
-    const int n_lights = S.n_lights;
-    unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0, n_in_wave = 0;
-    double ref_wave = 0.0;
-    const uint32_t B = batch_lanes_for(n, S.lane_fold);
-    const uint32_t n_batches = (n + B - 1) / B;
-    BatchCursor cursor(&cc->work_trace[kMaxBounce + 1][0]);       // a cursor row no bounce uses
-    for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
-        const uint32_t i = bi * B + lane_id();
-        bool alive = i < n && lane_id() < B;
-        Ray r{0, 0, 0, 0, 0, 0};
-        double w = 0.0; uint32_t slot = 0;
-        if (alive) {
-            const FT_CONST RayBuf& rays = fresh(K)->rays[k0 & 1];
-            r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i];
-        }
-        n_in_wave += (unsigned long long)__popcll(__ballot(alive));
-        double mult = 1.0;                                        // copies of this ray in the F# recursion (Shading.fs:109-139): L^k0, exactly
-        for (int k = 0; k < k0; ++k) mult *= (double)n_lights;
-        for (int depth = k0; __any(alive); ++depth, mult *= (double)n_lights) {
-            // ---- closest hit (k_closest)
-            Query<false> q;
-            q.active = alive; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
-            const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
-            bool overflow;
-            trace<false, MESH>(S, ro, q, lds, overflow, false);
-            n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && alive));
-            alive = alive && q.id0 != ID_MISS;
-            const unsigned long long hit_mask = __ballot(alive);
-            if (hit_mask == 0ull) break;
-            // ---- shade (k_shade)
-            Surface sf{{0, 0, 0}, {0, 1, 0}, 0, 0.0, 0.0};
-            bool lit = false;
-            unsigned long long sample = 0ull;
-            if (alive) {
-                sf = surface_at<FANCY>(S, ro, q.best_t, q.id0, q.id1);
-                lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
-                if (SOFT) sample = sample_id(&fresh(K)->gen, px, slot);
-            }
-            unsigned long long vis_lo, vis_hi;
-            light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, depth, false, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
-            MaterialV mat = material_at(S, sf.material);
-            if (FANCY) { if (alive && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
-            double cr, cg, cb;
-            shade_lights<FANCY, SOFT>(S, sf, mat, r, alive, lit, vis_lo, vis_hi, cr, cg, cb);
-            if (alive) {
-                const FT_CONST TailArgs* Ka = fresh(K);
-                double* acc = Ka->acc; const uint32_t acc_stride = Ka->acc_stride;
-                acc[slot] += w * cr; acc[(size_t)acc_stride + slot] += w * cg; acc[2 * (size_t)acc_stride + slot] += w * cb;
-            }
-            const bool spawn = lit && mat.reflectance > 0.0 && depth < max_depth;          // reflectionShader (Shading.fs:89-98), see k_shade
-            const uint32_t n_hit = (uint32_t)__popcll(hit_mask), n_spawn = (uint32_t)__popcll(__ballot(spawn));
-            n_hit_wave += n_hit; n_refl_wave += n_spawn;
-            ref_wave += mult * ((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit + (double)n_lights * (double)n_spawn);
-            if (spawn) {
-                const double k2 = 2.0 * dot3(r.dx, r.dy, r.dz, sf.n.x, sf.n.y, sf.n.z);
-                r = {sf.p.x, sf.p.y, sf.p.z, r.dx - k2 * sf.n.x, r.dy - k2 * sf.n.y, r.dz - k2 * sf.n.z};
-                w = w * (mat.reflectance * (double)n_lights);
-            }
-            alive = spawn;
-        }
-    }
-    RenderCounters* mine = my_stats(fresh(K)->fc);
-    wave_add(&mine->rays_shadow, n_shadow_wave);
-    wave_add(&mine->rays_reflect, n_refl_wave);
-    wave_add(&mine->hits_total, n_hit_wave);
-    wave_add(&mine->csg_overflow, n_ovf_wave);
-    wave_add(&mine->tail_in, n_in_wave);
-    wave_add(&mine->tail_rays, n_refl_wave);
-    wave_add(&mine->tail_hits, n_hit_wave);
-    wave_add(&mine->ref_equiv, ref_wave);
-}
-
 // Image.write's toByte (Image.fs:36; Math.clamp, Math.fs:12-16): clamp to [0, 1] (NaN passes the clamp), * 255, truncate.
 FT_DEV uint32_t to_byte(double x) {
     if (x > 1.0) x = 1.0; else if (x < 0.0) x = 0.0;
@@ -1964,20 +1841,6 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
 
 } // namespace
 
-typedef void (*ShadeKernel)(ShadeArgs);
-static ShadeKernel shade_variant(int v) {                          // bit 0 FANCY, bit 1 SOFT, bit 2 MESH
-    switch (v & 7) {
-        case 0: return k_shade<false, false, false>;
-        case 1: return k_shade<true, false, false>;
-        case 2: return k_shade<false, true, false>;
-        case 3: return k_shade<true, true, false>;
-        case 4: return k_shade<false, false, true>;
-        case 5: return k_shade<true, false, true>;
-        case 6: return k_shade<false, true, true>;
-        default: return k_shade<true, true, true>;
-    }
-}
-
 typedef void (*PrimaryKernel)(PrimaryArgs);
 static PrimaryKernel primary_variant(int v) {
     switch (v & 7) {
@@ -1992,33 +1855,23 @@ static PrimaryKernel primary_variant(int v) {
     }
 }
 
-typedef void (*TailKernel)(TailArgs);
-static TailKernel tail_variant(int v) {
+typedef void (*BounceKernel)(BounceArgs);
+static BounceKernel bounce_variant(int v) {
     switch (v & 7) {
-        case 0: return k_tail<false, false, false>;
-        case 1: return k_tail<true, false, false>;
-        case 2: return k_tail<false, true, false>;
-        case 3: return k_tail<true, true, false>;
-        case 4: return k_tail<false, false, true>;
-        case 5: return k_tail<true, false, true>;
-        case 6: return k_tail<false, true, true>;
-        default: return k_tail<true, true, true>;
+        case 0: return k_bounce<false, false, false>;
+        case 1: return k_bounce<true, false, false>;
+        case 2: return k_bounce<false, true, false>;
+        case 3: return k_bounce<true, true, false>;
+        case 4: return k_bounce<false, false, true>;
+        case 5: return k_bounce<true, false, true>;
+        case 6: return k_bounce<false, true, true>;
+        default: return k_bounce<true, true, true>;
     }
 }
 
 // ============================================================================================ launchers
 static int blocks_for(uint32_t n, int grid) { uint32_t need = (n + kBlock - 1) / kBlock; if (need < 1) need = 1; return (int)(need < (uint32_t)grid ? need : (uint32_t)grid); }
 
-void launch_closest(const Launch& L, const DevScene& S, RayBuf rays, HitBuf hits, uint32_t* hit_list, int bounce, uint32_t tail_threshold, FrameCounters* fc) {
-    const ClosestArgs a{S, rays, hits, hit_list, fc, bounce, tail_threshold};
-    if (L.variant & 4) hipLaunchKernelGGL(k_closest<true>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
-    else hipLaunchKernelGGL(k_closest<false>, dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
-}
-void launch_shade(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, HitBuf hits, const uint32_t* hit_list, RayBuf next, double* acc,
-                  uint32_t acc_stride, int bounce, int max_depth, FrameCounters* fc) {
-    const ShadeArgs a{S, gen, rays, hits, next, hit_list, acc, fc, acc_stride, bounce, max_depth};
-    hipLaunchKernelGGL(shade_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
-}
 void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint32_t acc_stride, int max_depth, FrameCounters* fc) {
     const PrimaryArgs a{S, gen, next, acc, fc, acc_stride, max_depth};
     hipLaunchKernelGGL(primary_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
@@ -2028,10 +1881,9 @@ void launch_classify(const Launch& L, const DevScene& S, const Primary& gen_list
     const uint32_t n_blocks = gen_list.n_pix / 64u;
     hipLaunchKernelGGL(k_classify, dim3((n_blocks + kClassifyBlock - 1u) / kClassifyBlock), dim3(kClassifyBlock), 0, L.stream, a);
 }
-void launch_tail(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays_even, RayBuf rays_odd, double* acc, uint32_t acc_stride,
-                 int max_depth, uint32_t threshold, FrameCounters* fc, int first_bounce) {
-    const TailArgs a{S, gen, {rays_even, rays_odd}, acc, fc, acc_stride, max_depth, threshold, first_bounce};
-    hipLaunchKernelGGL(tail_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
+void launch_bounce(const Launch& L, const DevScene& S, const Primary& gen, RayBuf rays, RayBuf next, double* acc, uint32_t acc_stride, int bounce, int max_depth, bool follow, FrameCounters* fc) {
+    const BounceArgs a{S, gen, rays, next, acc, fc, acc_stride, bounce, max_depth, follow ? 1 : 0};
+    hipLaunchKernelGGL(bounce_variant(L.variant), dim3(L.grid), dim3(kBlock), L.lds_bytes, L.stream, a);
 }
 void launch_resolve(const Launch& L, const ResolveArgs& a) {
     const uint32_t work = a.block_pos ? (a.n_blocks_total * 64u > a.n_pix_host ? a.n_blocks_total * 64u : a.n_pix_host) : a.n_pix_host;
@@ -2054,27 +1906,14 @@ void launch_debug_blocked(const Launch& L, const DevScene& S, const double* o, c
 // Resident workgroups per CU for the persistent grids (register- and LDS-limited).
 namespace ftk {
 static int clamp_blocks(int n) { return n < 1 ? 1 : (n > 8 ? 8 : n); }
-int occupancy_blocks_closest(size_t lds_bytes, int variant) {
-    int n = 0;
-    hipError_t e = (variant & 4) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<true>, kBlock, lds_bytes)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<false>, kBlock, lds_bytes);
-    if (e != hipSuccess) n = 2;
-    return clamp_blocks(n);
-}
-int occupancy_blocks_tail(size_t lds_bytes, int variant) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_variant(variant), kBlock, lds_bytes) != hipSuccess) n = 1;
-    return clamp_blocks(n);
-}
 int occupancy_blocks_primary(size_t lds_bytes, int variant) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, primary_variant(variant), kBlock, lds_bytes) != hipSuccess) n = 1;
     return clamp_blocks(n);
 }
-int occupancy_blocks_shade(size_t lds_bytes, int variant) {
+int occupancy_blocks_bounce(size_t lds_bytes, int variant) {
     int n = 0;
-    auto k = shade_variant(variant);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kBlock, lds_bytes) != hipSuccess) n = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bounce_variant(variant), kBlock, lds_bytes) != hipSuccess) n = 1;
     return clamp_blocks(n);
 }
 } // namespace ftk

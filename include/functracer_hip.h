@@ -121,9 +121,9 @@ typedef struct ft_stats {
     int32_t  n_launches;
     int32_t  n_chunks;
     uint64_t hits_total;     /* hits shaded over all bounces                                   */
-    uint64_t algorithmic_bytes_closest; /* the k_closest share of algorithmic_bytes (bounces >= 1) */
-    uint64_t algorithmic_bytes_shade;   /* the k_shade share (bounces >= 1)                    */
-    uint64_t rays_tail;      /* reflection rays followed by the tail kernel (handed over + spawned inside it) */
+    uint64_t algorithmic_bytes_closest; /* unused since ABI 2 (always 0)                       */
+    uint64_t algorithmic_bytes_shade;   /* the k_bounce share (bounces >= 1)                   */
+    uint64_t rays_tail;      /* unused since ABI 2 (always 0): kept so the layout of ABI 1 callers' struct prefix stays */
     uint64_t rays_primary_culled; /* primary rays (part of rays_primary) resolved as misses per 64-pixel block: the block's ray
                                    * bundle cannot reach any object, so they were never generated one by one          */
     uint64_t algorithmic_bytes_primary; /* the k_primary (fused bounce 0) share of algorithmic_bytes                          */
@@ -144,8 +144,8 @@ const char* ft_last_error(const ft_context* ctx);
  * CSG; default 32), "csg_auto_grow" (default 1: a blocking ft_render (and the ft_debug_* ray queries) whose hit lists overflow doubles that capacity, re-commits and renders the
  * frame again instead of returning FT_ERR_OVERFLOW; the error remains for lists that stop fitting in the LDS and for ft_render_enqueue), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around every
  * k_closest / k_shade launch, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
- * cannot reach any object are finished before any ray is generated; the bundle is bounded from the jitter pattern handed to ft_render, whatever its range), "tail_rays" (a bounce starting with fewer rays is finished by the tail
- * kernel in one launch; 0 = never; default 262144), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
+ * cannot reach any object are finished before any ray is generated; the bundle is bounded from the jitter pattern handed to ft_render, whatever its range), "level_hint" (default 1: a frame launches as many levels of the reflection tree as the
+ * previous frame of the same scene, size and samples had rays in, plus one, whose rays are followed to the end inside the launch; 0: always max_depth levels), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits), "bvh_builder" (1 = default: the exact BVH of top-level-Leaf meshes is a linear BVH built on the
  * device at commit; 0: the host's recursive median split).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
@@ -252,9 +252,9 @@ int32_t ft_create_host_only(ft_context** out);
 int32_t ft_debug_scene_info(ft_context* ctx, int64_t out[12]);
 int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9],
                        double above[18], int32_t* n_above, double below[18], int32_t* n_below);
-/* HIP-event time per stage over the last ft_render: index 4 primary (bounce 0 fused: generate + closest + shade), 1 closest and
- * 2 shade of the later bounces (2 also holds the tail kernel); with "timing" = 2 also 3 blend and 0 the rest (memsets,
- * classification, statistics); otherwise 0 = everything that is not bracketed, 3 = 0. */
+/* HIP-event time per stage over the last ft_render: index 4 primary (bounce 0 fused: generate + closest + shade), 2 the later
+ * bounces (one k_bounce per level; one bracket around them all, or with "timing" = 2 one per level), 3 resolve and 0 the rest (the
+ * fill, classification) with "timing" = 2; otherwise 0 = everything that is not bracketed and 3 = 0.  Index 1 is unused. */
 int32_t ft_get_kernel_times(ft_context* ctx, double ms[5], int32_t launches[5]);
 
 /* Image.write's toByte (Image.fs:36): clamp to [0,1], *255, truncate; alpha = 255. */

@@ -663,26 +663,37 @@ def test_image_textures_match_oracle(hip):
 
 
 @pytest.mark.parametrize("name", ["hollow-sphere", "night-house", "sample-soft"])
-def test_tail_kernel_changes_no_pixel_and_no_count(hip, name):
-    """k_tail finishes the late bounces in one launch: same device functions, same order per sample, so the frame and every
-    ray count must equal the staged bounces bit for bit wherever the hand-over happens."""
+def test_levels_launched_change_no_pixel_and_no_count(hip, name):
+    """One k_bounce per level of the reflection tree; the host launches as many levels as the previous frame of the same signature
+    needed (+ 1) and the last one follows what it still spawns in registers.  Every way of cutting the levels - all of them, the hint,
+    a hint that is too short because the previous frame looked at nothing reflective - gives the same frame and the same counts."""
     p = _load(name)
     p.lower(hip)
     jit = ft.jitter_pattern(2)
+    away = ft.make_camera(tuple(p.camera.o), tuple(2 * o - l for o, l in zip(p.camera.o, p.camera.look_at)), tuple(p.camera.up), p.camera.fov_y, p.camera.aspect_ratio)
     frames, stats = [], []
     try:
-        for threshold in (0, 1 << 30, 3000):
-            hip.set_option("tail_rays", threshold)
-            img, st = hip.render(p.camera, 160, 90, 2, jit)
-            frames.append(img)
-            stats.append(st)
+        hip.set_option("level_hint", 0)
+        frames.append(hip.render(p.camera, 160, 90, 2, jit)); stats.append(frames[-1][1])          # every level launched
+        hip.set_option("level_hint", 1)
+        hip.render(p.camera, 160, 90, 2, jit)                                                      # sets the hint
+        frames.append(hip.render(p.camera, 160, 90, 2, jit)); stats.append(frames[-1][1])          # hinted
+        hip.render(away, 160, 90, 2, jit)                                                          # same signature, shallow frame: the hint shrinks
+        frames.append(hip.render(p.camera, 160, 90, 2, jit)); stats.append(frames[-1][1])          # the hint is too short: the last level follows
+        for depth in (0, 1, 3):                                                                    # the recursion limit cuts the levels too
+            a, sa = hip.render(p.camera, 160, 90, 2, jit, max_depth=depth)
+            hip.set_option("level_hint", 0)
+            b, sb = hip.render(p.camera, 160, 90, 2, jit, max_depth=depth)
+            hip.set_option("level_hint", 1)
+            assert np.array_equal(a, b) and sa["rays_reflect"] == sb["rays_reflect"]
     finally:
-        hip.set_option("tail_rays", 262144)
-    assert stats[0]["rays_tail"] == 0 and stats[1]["rays_tail"] > 0
-    for img, st in zip(frames[1:], stats[1:]):
-        assert np.array_equal(img, frames[0])
+        hip.set_option("level_hint", 1)
+    assert stats[0]["rays_reflect"] > 0
+    for (img, _), st in zip(frames[1:], stats[1:]):
+        assert np.array_equal(img, frames[0][0])
         for key in ("rays_shadow", "rays_reflect", "rays_traced", "hits_total", "rays_reference_equivalent"):
             assert st[key] == stats[0][key], key
+    assert stats[2]["n_launches"] < stats[0]["n_launches"]
 
 
 @pytest.mark.parametrize("name", ["bunny", "moon", "hollow-sphere", "bunny-bsp12", "sample-det"])

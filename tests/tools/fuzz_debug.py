@@ -23,9 +23,9 @@ for seed in [int(a) for a in sys.argv[1:]]:
     want, ost = orc.render(cam, 96, 64, 2, jit, seed=ft.DEFAULT_SEED)
     kinds = [c[0] for c in r.calls]
     print(f"seed {seed}: lights", [k for k in kinds if k.startswith("add_")], "nan px oracle", int(np.isnan(want).any(-1).sum()))
-    for name, opts in [("default", {}), ("incoherent", {"coherent_waves": 0}), ("no classify", {"classify_pixels": 0}), ("depth0", {"max_depth": 0})]:
-        for k in ("classify_pixels", "tail_rays", "coherent_waves"):
-            hip.set_option(k, {"classify_pixels": 1, "tail_rays": 262144, "coherent_waves": 1}[k])
+    for name, opts in [("default", {}), ("incoherent", {"coherent_waves": 0}), ("no classify", {"classify_pixels": 0}), ("all levels", {"level_hint": 0}), ("depth0", {"max_depth": 0})]:
+        for k in ("classify_pixels", "level_hint", "coherent_waves"):
+            hip.set_option(k, 1)
         md = 8
         for k, v in opts.items():
             if k == "max_depth":
@@ -44,4 +44,4 @@ for seed in [int(a) for a in sys.argv[1:]]:
         if name == "default" and bad.any():
             x, y = int(xs[0]), int(ys[0])
             print("      first:", (x, y), "gpu", got[y, x], "oracle", w2[y, x])
-    hip.set_option("classify_pixels", 1); hip.set_option("tail_rays", 262144); hip.set_option("coherent_waves", 1)
+    hip.set_option("classify_pixels", 1); hip.set_option("level_hint", 1); hip.set_option("coherent_waves", 1)
