@@ -1067,10 +1067,10 @@ struct BatchCursor {
 FT_DEV uint32_t batch_lanes_for(uint32_t n, int lane_fold, int n_simd) {
     // A batch costs a fixed part (the walk through the scene program: ~17 us of issue time on an otherwise idle SIMD for one
     // incoherent ray) plus ~1 us per further ray, and the SIMD, not the wave, is what that time is spent on.  So the rays are spread
-    // only as far as it takes to give every SIMD one batch: the narrowest batches that still fit in one round.  (Spreading until
-    // every WAVE had a batch made a level of 15 K rays 7.5 K two-ray batches: 119 us instead of ~35.)
+    // only until every SIMD has a batch or two (measured on hollow-sphere x1: one to two batches per SIMD 0.89 ms, at most one 0.95,
+    // two to four 0.95, one per WAVE - round 1's rule, a level of 15 K rays as 7.5 K two-ray batches - 0.98).
     uint32_t b = 64u / (uint32_t)lane_fold;                         // folded lanes lend their LDS columns to the live ones (HitList)
-    while (b > 1u && n <= (b >> 1) * (uint32_t)n_simd) b >>= 1;
+    while (b > 1u && n < b * (uint32_t)n_simd) b >>= 1;
     return b;
 }
 
