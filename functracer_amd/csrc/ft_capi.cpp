@@ -18,7 +18,7 @@
 #include "ft_scene.h"
 
 namespace ftk {
-int occupancy_blocks_primary(size_t lds_bytes, int variant);
+int occupancy_blocks_primary(size_t lds_bytes, int* variant);
 int occupancy_blocks_bounce(size_t lds_bytes, int variant);
 }
 
@@ -776,7 +776,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;   // FANCY
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
     if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
-    ftk::Launch Lp{c->stream, c->n_cu * ftk::occupancy_blocks_primary(lds, variant), lds, variant};
+    int variant_p = variant;
+    const int blocks_p = ftk::occupancy_blocks_primary(lds, &variant_p);
+    ftk::Launch Lp{c->stream, c->n_cu * blocks_p, lds, variant_p};
     ftk::Launch Lb{c->stream, c->n_cu * ftk::occupancy_blocks_bounce(lds, variant), lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};

@@ -114,7 +114,7 @@ struct Primary {
 // Bounce 0 fused (k_primary): generate the primary rays of the chunk, closest hit, shadow queries, shaders, reflection spawn, and
 // one colour per sample stored into acc (Colour.Zero for a miss).
 void launch_primary(const Launch& L, const DevScene& S, const Primary& gen, RayBuf next, double* acc, uint32_t acc_stride, int max_depth, FrameCounters* fc);
-int occupancy_blocks_primary(size_t lds_bytes, int variant);
+int occupancy_blocks_primary(size_t lds_bytes, int* variant);   // may add bit 3 to *variant: the lean kernel built for five workgroups per CU
 // One level of the reflection tree (bounce k >= 1) fused (k_bounce): closest hit, shadow queries, shaders and accumulation for every
 // ray of rays (n = fc->cc.n_rays[bounce]); the level's reflection rays are compacted into `next`, or, with `follow`, followed to their
 // end inside the launch (the last level the host launches).  A launch that finds no rays returns at once.

@@ -1314,11 +1314,17 @@ struct PrimaryArgs {
 // Resident workgroups per CU (measured on the config scenes, profiles/r02_a_fused_vs_split.txt: 2 -> 3 -> 4 is faster at every
 // step although 4 leaves 128 registers per lane and the compiler parks cold state in scratch: the path waits on dependent scalar
 // loads, and a fourth wave per SIMD covers more of that than the spill traffic costs).
+// A fifth wave pays on the leanest variant only (no meshes, no soft lights; measured: night-house-det 3.60 -> 3.30 ms, the others even
+// or worse), and only where the scene's LDS lets five workgroups live on a CU: hollow-sphere's hit lists allow four, and the
+// five-workgroup build - fewer registers, more scratch - costs it 3 %.  So the lean variant exists twice and the host picks.
 #ifndef FT_PRIMARY_BLOCKS
 #define FT_PRIMARY_BLOCKS 4
 #endif
-template <bool FANCY, bool SOFT, bool MESH>
-__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_PRIMARY_BLOCKS) void k_primary(PrimaryArgs) {
+#ifndef FT_LEAN_BLOCKS
+#define FT_LEAN_BLOCKS 5
+#endif
+template <bool FANCY, bool SOFT, bool MESH, int BLOCKS>
+__global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST PrimaryArgs* K = kernel_args<PrimaryArgs>();
     const Scene S = scene_view(K->S);
@@ -1432,7 +1438,10 @@ struct BounceArgs {
 #define FT_BOUNCE_BLOCKS 4
 #endif
 template <bool FANCY, bool SOFT, bool MESH>
-__global__ __launch_bounds__(kBlock, FANCY ? 2 : FT_BOUNCE_BLOCKS) void k_bounce(BounceArgs) {
+#ifndef FT_BOUNCE_LEAN
+#define FT_BOUNCE_LEAN FT_BOUNCE_BLOCKS
+#endif
+__global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEAN : FT_BOUNCE_BLOCKS)) void k_bounce(BounceArgs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const FT_CONST BounceArgs* K = kernel_args<BounceArgs>();
     const int bounce = K->bounce;
@@ -1842,16 +1851,17 @@ __global__ __launch_bounds__(kBlock) void k_debug_blocked(DevScene Sg, const dou
 } // namespace
 
 typedef void (*PrimaryKernel)(PrimaryArgs);
-static PrimaryKernel primary_variant(int v) {
-    switch (v & 7) {
-        case 0: return k_primary<false, false, false>;
-        case 1: return k_primary<true, false, false>;
-        case 2: return k_primary<false, true, false>;
-        case 3: return k_primary<true, true, false>;
-        case 4: return k_primary<false, false, true>;
-        case 5: return k_primary<true, false, true>;
-        case 6: return k_primary<false, true, true>;
-        default: return k_primary<true, true, true>;
+static PrimaryKernel primary_variant(int v) {                      // bit 0 FANCY, bit 1 SOFT, bit 2 MESH, bit 3: the lean variant built for five workgroups per CU
+    switch (v & 15) {
+        case 0: return k_primary<false, false, false, FT_PRIMARY_BLOCKS>;
+        case 8: return k_primary<false, false, false, FT_LEAN_BLOCKS>;
+        case 1: case 9: return k_primary<true, false, false, 2>;
+        case 2: case 10: return k_primary<false, true, false, FT_PRIMARY_BLOCKS>;
+        case 3: case 11: return k_primary<true, true, false, 2>;
+        case 4: case 12: return k_primary<false, false, true, FT_PRIMARY_BLOCKS>;
+        case 5: case 13: return k_primary<true, false, true, 2>;
+        case 6: case 14: return k_primary<false, true, true, FT_PRIMARY_BLOCKS>;
+        default: return k_primary<true, true, true, 2>;
     }
 }
 
@@ -1906,9 +1916,13 @@ void launch_debug_blocked(const Launch& L, const DevScene& S, const double* o, c
 // Resident workgroups per CU for the persistent grids (register- and LDS-limited).
 namespace ftk {
 static int clamp_blocks(int n) { return n < 1 ? 1 : (n > 8 ? 8 : n); }
-int occupancy_blocks_primary(size_t lds_bytes, int variant) {
+// Resident workgroups per CU of k_primary for this scene; *variant gains bit 3 when the five-workgroup build of the lean variant fits.
+int occupancy_blocks_primary(size_t lds_bytes, int* variant) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, primary_variant(variant), kBlock, lds_bytes) != hipSuccess) n = 1;
+    if ((*variant & 7) == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, primary_variant(8), kBlock, lds_bytes) == hipSuccess && n >= FT_LEAN_BLOCKS) { *variant |= 8; return clamp_blocks(n); }
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, primary_variant(*variant), kBlock, lds_bytes) != hipSuccess) n = 1;
     return clamp_blocks(n);
 }
 int occupancy_blocks_bounce(size_t lds_bytes, int variant) {
