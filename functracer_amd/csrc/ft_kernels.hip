@@ -581,8 +581,9 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
     int cur = wide_root;
     // The boxes of a node's four children live in the node (ft_flat.h): one scalar-load round trip decides four subtrees.
     const unsigned long long live0 = __ballot(alive);
-    const bool fwd[3] = {2 * __popcll(__ballot(alive && r.dx >= 0.0)) >= __popcll(live0), 2 * __popcll(__ballot(alive && r.dy >= 0.0)) >= __popcll(live0),
-                         2 * __popcll(__ballot(alive && r.dz >= 0.0)) >= __popcll(live0)};   // majority direction per axis: which child is nearer
+    // majority direction per axis (bit a set: most live rays travel towards +a): which child is nearer
+    const uint32_t oct = (2 * __popcll(__ballot(alive && r.dx >= 0.0)) >= __popcll(live0) ? 1u : 0u) | (2 * __popcll(__ballot(alive && r.dy >= 0.0)) >= __popcll(live0) ? 2u : 0u) |
+                         (2 * __popcll(__ballot(alive && r.dz >= 0.0)) >= __popcll(live0) ? 4u : 0u);
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         if (cur >= 0) {
@@ -604,21 +605,24 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                 const bool enter = alive && tmax >= fmax(tmin, 0.0) && tmin <= bound;
                 m[c] = ch[c] == INT32_MIN ? 0ull : __ballot(enter);
             }
-            // visiting order, nearest first by the majority directions: halves by the node's axis, slots within a half by the child's
-            const bool left_half_first = fwd[axes & 3u], l_fwd = fwd[(axes >> 8) & 3u], r_fwd = fwd[(axes >> 16) & 3u];
-            const int l0 = l_fwd ? 0 : 1, l1 = l_fwd ? 1 : 0, r0 = r_fwd ? 2 : 3, r1 = r_fwd ? 3 : 2;
-            const int seq[4] = {left_half_first ? l0 : r0, left_half_first ? l1 : r1, left_half_first ? r0 : l0, left_half_first ? r1 : l1};
-            int next = kDone;
-#pragma unroll
-            for (int j = 3; j >= 0; --j) {                          // far to near: what was nearest so far goes on the stack
-                const int c = seq[j];
-                const unsigned long long mc = c == 0 ? m[0] : c == 1 ? m[1] : c == 2 ? m[2] : m[3];
-                if (mc) {
-                    if (next != kDone) { stack_lanes = ((int)lane_id() == sp) ? next : stack_lanes; ++sp; }
-                    next = c == 0 ? ch[0] : c == 1 ? ch[1] : c == 2 ? ch[2] : ch[3];
-                }
+            // Visiting order, nearest first by the majority directions: halves by the node's axis, slots within a half by the child's.
+            // The entered children go on the stack far to near and the common pop below takes the nearest; one of eight fixed
+            // sequences is picked by three bits, so every push names its child statically (selecting m[c] / ch[c] by a computed c
+            // cost ~250 scalar instructions per node - eight-byte select chains - against ~80 vector ones: the scalar pipe, one
+            // per CU, was the busier half of this kernel).
+            const uint32_t order = (((oct >> (axes & 3u)) & 1u) << 2) | (((oct >> ((axes >> 8) & 3u)) & 1u) << 1) | ((oct >> ((axes >> 16) & 3u)) & 1u);
+#define FT_PUSH(c) do { if (m[c]) { stack_lanes = ((int)lane_id() == sp) ? ch[c] : stack_lanes; ++sp; } } while (0)
+            switch (order) {                                        // bit 2: left half first; bit 1: slot 0 before 1; bit 0: slot 2 before 3
+                case 7: FT_PUSH(3); FT_PUSH(2); FT_PUSH(1); FT_PUSH(0); break;     // near to far 0 1 2 3
+                case 6: FT_PUSH(2); FT_PUSH(3); FT_PUSH(1); FT_PUSH(0); break;     // 0 1 3 2
+                case 5: FT_PUSH(3); FT_PUSH(2); FT_PUSH(0); FT_PUSH(1); break;     // 1 0 2 3
+                case 4: FT_PUSH(2); FT_PUSH(3); FT_PUSH(0); FT_PUSH(1); break;     // 1 0 3 2
+                case 3: FT_PUSH(1); FT_PUSH(0); FT_PUSH(3); FT_PUSH(2); break;     // 2 3 0 1
+                case 2: FT_PUSH(1); FT_PUSH(0); FT_PUSH(2); FT_PUSH(3); break;     // 3 2 0 1
+                case 1: FT_PUSH(0); FT_PUSH(1); FT_PUSH(3); FT_PUSH(2); break;     // 2 3 1 0
+                default: FT_PUSH(0); FT_PUSH(1); FT_PUSH(2); FT_PUSH(3); break;    // 3 2 1 0
             }
-            if (next != kDone) { cur = next; continue; }
+#undef FT_PUSH
         } else {
             const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
             for (uint32_t k = 0; k < count; ++k) {                 // wave-uniform: scalar loads
