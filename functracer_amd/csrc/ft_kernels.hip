@@ -574,6 +574,7 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                  ivz = fabs(r.dz) < 1e-150 ? copysign(1e150, r.dz) : 1.0 / r.dz;
     const double oix = r.ox * ivx, oiy = r.oy * ivy, oiz = r.oz * ivz;
     double bound = ANY ? q.max_dist : q.best_t;
+    double reach = alive ? bound : -__builtin_inf();               // how far a box may lie and still matter to this lane: nowhere for a dead one
     uint32_t best_tri = 0xFFFFFFFFu;
     bool found = false;
     int stack_lanes = 0;                                           // lane i holds stack entry i (at most 3 per level of the wide tree)
@@ -588,7 +589,9 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
         cur = __builtin_amdgcn_readfirstlane(cur);
         if (cur >= 0) {
             cdp nd = S.wide + (unsigned long long)kWideNodeDoubles * (uint32_t)cur;
-            cip ch = reinterpret_cast<cip>(nd + 24);
+            // children and axes are read up front, with the first boxes: fetched one by one behind each child's test, every
+            // one of them was a scalar-load round trip of its own
+            const int32_t ch[4] = {reinterpret_cast<cip>(nd + 24)[0], reinterpret_cast<cip>(nd + 24)[1], reinterpret_cast<cip>(nd + 24)[2], reinterpret_cast<cip>(nd + 24)[3]};
             const uint32_t axes = reinterpret_cast<cup>(nd + 26)[0];
             unsigned long long m[4];
 #pragma unroll
@@ -602,7 +605,8 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                 tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
                 t0 = __builtin_fma(bx[2], ivz, -oiz); t1 = __builtin_fma(bx[5], ivz, -oiz);
                 tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
-                const bool enter = alive && tmax >= fmax(tmin, 0.0) && tmin <= bound;
+                // dead lanes carry reach = -inf, so the two comparisons are the whole test (no short-circuit: no exec-mask games)
+                const bool enter = (tmax >= fmax(tmin, 0.0)) & (tmin <= reach);
                 m[c] = ch[c] == INT32_MIN ? 0ull : __ballot(enter);
             }
             // Visiting order, nearest first by the majority directions: halves by the node's axis, slots within a half by the child's.
@@ -611,7 +615,8 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
             // cost ~250 scalar instructions per node - eight-byte select chains - against ~80 vector ones: the scalar pipe, one
             // per CU, was the busier half of this kernel).
             const uint32_t order = (((oct >> (axes & 3u)) & 1u) << 2) | (((oct >> ((axes >> 8) & 3u)) & 1u) << 1) | ((oct >> ((axes >> 16) & 3u)) & 1u);
-#define FT_PUSH(c) do { if (m[c]) { stack_lanes = ((int)lane_id() == sp) ? ch[c] : stack_lanes; ++sp; } } while (0)
+            // a push is one v_writelane at the top slot (free when nothing is entered: the write is then simply not kept) and a scalar add
+#define FT_PUSH(c) do { asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stack_lanes) : "s"(ch[c]), "s"(sp) : "m0"); sp += m[c] != 0ull ? 1 : 0; } while (0)
             switch (order) {                                        // bit 2: left half first; bit 1: slot 0 before 1; bit 0: slot 2 before 3
                 case 7: FT_PUSH(3); FT_PUSH(2); FT_PUSH(1); FT_PUSH(0); break;     // near to far 0 1 2 3
                 case 6: FT_PUSH(2); FT_PUSH(3); FT_PUSH(1); FT_PUSH(0); break;     // 0 1 3 2
@@ -628,10 +633,10 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
             for (uint32_t k = 0; k < count; ++k) {                 // wave-uniform: scalar loads
                 double t;
                 if (alive && tri_hit(S.tris + 9ull * (first + k), r, t)) {
-                    if (ANY) { if (t < bound) { q.blocked = true; alive = false; } }
+                    if (ANY) { if (t < bound) { q.blocked = true; alive = false; reach = -__builtin_inf(); } }
                     else {
                         const uint32_t orig = S.tri_orig[first + k];
-                        if (t < bound || (found && t == bound && orig < best_tri)) { bound = t; best_tri = orig; found = true; }
+                        if (t < bound || (found && t == bound && orig < best_tri)) { bound = t; reach = t; best_tri = orig; found = true; }
                     }
                 }
             }
