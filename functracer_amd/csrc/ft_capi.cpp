@@ -48,6 +48,7 @@ struct ft_context {
     double commit_ms[4] = {0, 0, 0, 0};   // last ft_scene_commit: flatten on the host, device BVH builds, uploads + the rest, BVH height (not a time)
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
+    int wave_samples_log2 = -1;     // bounce-0 wavefronts take 2^this samples of 64 / 2^this pixels when the sample count allows (option wave_samples); -1: by scene
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
     int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
@@ -263,6 +264,12 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "chunk_samples")) { if (value < 64) return FT_ERR_INVALID; c->chunk_samples = value; for (ft_context* p : c->peers) p->chunk_samples = value; return FT_OK; }
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
     if (!std::strcmp(key, "coherent_waves")) { c->coherent_waves = value != 0; c->dev_scene.coherent_waves = value != 0 ? 1 : 0; for (ft_context* p : c->peers) { p->coherent_waves = value != 0; p->dev_scene.coherent_waves = c->dev_scene.coherent_waves; } return FT_OK; }
+    if (!std::strcmp(key, "wave_samples")) {
+        int l = 0; while ((1ll << l) < value) ++l;                 // 0: chosen by scene (the default); 1, 2, 4 ... 64: that many samples per wavefront
+        if (value < 0 || value > 64 || (value > 0 && (1ll << l) != value)) return FT_ERR_INVALID;
+        if (value == 0) l = -1;
+        c->wave_samples_log2 = l; for (ft_context* p : c->peers) p->wave_samples_log2 = l; return FT_OK;
+    }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
@@ -776,6 +783,11 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;   // FANCY
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
     if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
+    // Samples per bounce-0 wavefront (k_primary).  Measured at 1080p x 16: narrow bundles of 4 pixels x 16 samples pay where a wave walks
+    // a BVH (bunny through BSP leaves 1.46 -> 1.29 ms, bunny 0.363 -> 0.358); elsewhere their scattered 32-byte colour stores cost more
+    // than the narrower bundle saves (moon 1.28 -> 1.35 ms) and 16 pixels x 4 samples (whole 128-byte lines) is the better deal
+    // (night-house 4.63 -> 4.47 ms, moon 1.29).
+    c->dev_scene.wave_samples_log2 = c->wave_samples_log2 >= 0 ? c->wave_samples_log2 : ((variant & 4) ? 4 : 2);
     int variant_p = variant;
     const int blocks_p = ftk::occupancy_blocks_primary(lds, &variant_p);
     ftk::Launch Lp{c->stream, c->n_cu * blocks_p, lds, variant_p};

@@ -38,6 +38,7 @@ struct DevScene {
     int32_t n_items, n_cull_rows;  // n_cull_rows < 0: pre-test disabled
     int32_t csg_rows, lane_fold;   // LDS rows per hit-list column and lanes folded together (see HitList): csg_cap <= csg_rows * lane_fold
     int32_t n_simd;                // SIMDs of the device (CUs x 4): how far few rays are spread (batch_lanes_for)
+    int32_t wave_samples_log2;     // a bounce-0 wavefront takes up to 2^this samples of 64 / 2^this pixels (k_primary), 0: one sample of 64 pixels
     int32_t coherent_waves;        // 1 (default): bounce-0 wavefronts use the bundle paths (cone cull, packet traversal); 0: every wave is treated as incoherent (diagnostic)   // sum over lights of the shadow rays the reference casts per hit
 };
 

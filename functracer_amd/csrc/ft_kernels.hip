@@ -587,6 +587,7 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                          (2 * __popcll(__ballot(alive && r.dz >= 0.0)) >= __popcll(live0) ? 4u : 0u);
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
+        sp = __builtin_amdgcn_readfirstlane(sp);                    // wave-uniform by construction; said here so that the stack arithmetic stays on the scalar unit
         if (cur >= 0) {
             cdp nd = S.wide + (unsigned long long)kWideNodeDoubles * (uint32_t)cur;
             // children and axes are read up front, with the first boxes: fetched one by one behind each child's test, every
@@ -606,8 +607,9 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                 t0 = __builtin_fma(bx[2], ivz, -oiz); t1 = __builtin_fma(bx[5], ivz, -oiz);
                 tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
                 // dead lanes carry reach = -inf, so the two comparisons are the whole test (no short-circuit: no exec-mask games)
-                const bool enter = (tmax >= fmax(tmin, 0.0)) & (tmin <= reach);
-                m[c] = ch[c] == INT32_MIN ? 0ull : __ballot(enter);
+                // (one ballot per comparison: the compiler turns a ballot of anything but a bare comparison into a select and a second compare);
+                // an absent child's box is tested like any other and dropped here, so that no branch stands between the node's loads
+                m[c] = __builtin_amdgcn_ballot_w64(tmax >= fmax(tmin, 0.0)) & __builtin_amdgcn_ballot_w64(tmin <= reach) & (ch[c] == INT32_MIN ? 0ull : ~0ull);
             }
             // Visiting order, nearest first by the majority directions: halves by the node's axis, slots within a half by the child's.
             // The entered children go on the stack far to near and the common pop below takes the nearest; one of eight fixed
@@ -615,8 +617,12 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
             // cost ~250 scalar instructions per node - eight-byte select chains - against ~80 vector ones: the scalar pipe, one
             // per CU, was the busier half of this kernel).
             const uint32_t order = (((oct >> (axes & 3u)) & 1u) << 2) | (((oct >> ((axes >> 8) & 3u)) & 1u) << 1) | ((oct >> ((axes >> 16) & 3u)) & 1u);
-            // a push is one v_writelane at the top slot (free when nothing is entered: the write is then simply not kept) and a scalar add
-#define FT_PUSH(c) do { asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stack_lanes) : "s"(ch[c]), "s"(sp) : "m0"); sp += m[c] != 0ull ? 1 : 0; } while (0)
+            // a push is one v_writelane at the top slot (free when nothing is entered: the write is then simply not kept) and a scalar add;
+            // the lane select goes through m0 (one scalar operand per vector instruction), which the compiler reserves and nothing else here uses
+            // (naming it as clobbered keeps the operands out of it; the compiler remarks that the register is reserved)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#define FT_PUSH(c) asm("s_mov_b32 m0, %1\n\tv_writelane_b32 %0, %2, m0\n\ts_cmp_lg_u64 %3, 0\n\ts_addc_u32 %1, %1, 0" : "+v"(stack_lanes), "+s"(sp) : "s"(ch[c]), "s"(m[c]) : "m0", "scc")
             switch (order) {                                        // bit 2: left half first; bit 1: slot 0 before 1; bit 0: slot 2 before 3
                 case 7: FT_PUSH(3); FT_PUSH(2); FT_PUSH(1); FT_PUSH(0); break;     // near to far 0 1 2 3
                 case 6: FT_PUSH(2); FT_PUSH(3); FT_PUSH(1); FT_PUSH(0); break;     // 0 1 3 2
@@ -628,6 +634,7 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                 default: FT_PUSH(0); FT_PUSH(1); FT_PUSH(2); FT_PUSH(3); break;    // 3 2 1 0
             }
 #undef FT_PUSH
+#pragma clang diagnostic pop
         } else {
             const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
             for (uint32_t k = 0; k < count; ++k) {                 // wave-uniform: scalar loads
@@ -1160,15 +1167,11 @@ FT_DEV uint32_t primary_pixel(PrimaryArg g, const Pix& px, uint32_t i) {   // th
     const uint32_t s = div_by(i, px.inv), pl = i - s * px.n;
     return list_pixel(g, g->pix_base + pl);
 }
-// `uniform_s`: all 64 lanes of the batch share one jitter offset (n_pix is a multiple of 64): it is then read
-// through a scalar load, which does not queue behind the wave's outstanding vector stores.
-FT_DEV Ray primary_ray_from(PrimaryArg g, const Pix& count, uint32_t i, uint32_t pid, bool uniform_s) {
+FT_DEV Ray primary_ray_from(PrimaryArg g, const Pix& count, uint32_t i, uint32_t pid) {
     const uint32_t s = div_by(i, count.inv);
     const uint32_t py = div_by(pid, g->inv_stride), px = pid - py * g->stride;
     const double centre_x = g->cam.tlx + (double)px * g->cam.pw, centre_y = g->cam.tly - (double)py * g->cam.ph;
-    double ox, oy;
-    if (uniform_s) { cdp J = to_const_as(g->jitter) + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)s); ox = J[0]; oy = J[1]; }
-    else { ox = g->jitter[2 * s]; oy = g->jitter[2 * s + 1]; }
+    const double ox = g->jitter[2 * s], oy = g->jitter[2 * s + 1];
     const double jx = centre_x + ox * g->cam.pw, jy = centre_y + oy * g->cam.ph;
     Ray r{g->cam.o[0], g->cam.o[1], g->cam.o[2],
           (g->cam.k[0] + jx * g->cam.i[0]) + jy * g->cam.j[0], (g->cam.k[1] + jx * g->cam.i[1]) + jy * g->cam.j[1], (g->cam.k[2] + jx * g->cam.i[2]) + jy * g->cam.j[2]};
@@ -1345,23 +1348,37 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
     const uint32_t B = batch_lanes_for(n, S.lane_fold, S.n_simd);
     const uint32_t n_batches = (n + B - 1) / B;
-    const bool uniform_s = B == 64u && (n_pix & 63u) == 0u;
+    const bool whole_blocks = B == 64u && (n_pix & 63u) == 0u;
     const bool coherent = K->S.coherent_waves != 0;
+    // Which 64 samples a wavefront takes.  Slots are numbered sample plane by sample plane (s * n_pix + pixel) and a batch of 64
+    // consecutive ones is one 8x8 pixel block under one jitter offset.  When the sample count has a power of two G in it, the G
+    // batches of one block under G consecutive offsets are dealt out the other way round: each takes 64 / G of the block's pixels
+    // under all G offsets - a bundle 1 / G as wide on the image plane, which enters fewer BVH nodes and passes fewer cull tests
+    // per ray.  Only the dealing changes: a slot's ray, its random streams and its place in acc are the same.
+    uint32_t group_log2 = 0;
+    if (whole_blocks) { const uint32_t spp = (uint32_t)K->gen.spp, cap = (uint32_t)K->S.wave_samples_log2; while (group_log2 < cap && !((spp >> group_log2) & 1u)) ++group_log2; }
+    const uint32_t n_blocks = n_pix >> 6;
+    const double inv_blocks = 1.0 / (double)(n_blocks ? n_blocks : 1u);
+    auto slot_of = [&](uint32_t batch) -> uint32_t {
+        if (group_log2 == 0) return batch * B + lane_id();
+        const uint32_t s = div_by(batch, inv_blocks), blk = batch - s * n_blocks, k = s & ((1u << group_log2) - 1u), ppw_log2 = 6u - group_log2;
+        return ((s - k) + (lane_id() >> ppw_log2)) * n_pix + (blk << 6) + (k << ppw_log2) + (lane_id() & ((1u << ppw_log2) - 1u));
+    };
     BatchCursor cursor(&cc->work_trace[0][0]);
     uint32_t bi = cursor.grab(), bi_next = cursor.grab();
     uint32_t pid_next = 0;
-    if (bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, px, bi * B + lane_id());
+    if (bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, px, slot_of(bi));
     for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
-        const uint32_t i = bi * B + lane_id();
+        const uint32_t i = slot_of(bi);
         const uint32_t pid = pid_next;
         const bool active = i < n && lane_id() < B;
         // ---- closest hit; the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
         Ray ro{0, 0, 0, 0, 0, 0};
         {
             const FT_CONST PrimaryArgs* Kb = fresh(K);              // camera, pixel list: loaded here, dead before the trace
-            if (bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, px, bi_next * B + lane_id());
+            if (bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, px, slot_of(bi_next));
             if (active) {
-                const Ray r = primary_ray_from(&Kb->gen, px, i, pid, uniform_s);
+                const Ray r = primary_ray_from(&Kb->gen, px, i, pid);
                 ro = {r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
             }
         }
@@ -1389,7 +1406,7 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
             if (FANCY) { if (hit && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
             // the view ray is generated again here rather than kept in registers across the shadow traces (same arithmetic, same value)
             const FT_CONST PrimaryArgs* K2 = fresh(K);
-            const Ray rv = hit ? primary_ray_from(&K2->gen, px, i, pid, uniform_s) : Ray{0, 0, 0, 0, 0, 0};
+            const Ray rv = hit ? primary_ray_from(&K2->gen, px, i, pid) : Ray{0, 0, 0, 0, 0, 0};
             shade_lights<FANCY, SOFT>(S, sf, mat, rv, hit, lit, vis_lo, vis_hi, cr, cg, cb);
             // reflectionShader (Shading.fs:89-98), see k_bounce: one ray of weight L * reflectance stands for the L identical sub-traces
             const bool spawn = lit && mat.reflectance > 0.0 && 0 < K2->max_depth;

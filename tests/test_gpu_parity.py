@@ -696,6 +696,36 @@ def test_levels_launched_change_no_pixel_and_no_count(hip, name):
     assert stats[2]["n_launches"] < stats[0]["n_launches"]
 
 
+@pytest.mark.parametrize("name", ["bunny", "night-house", "hollow-sphere", "sample-soft"])
+def test_samples_per_wavefront_change_no_pixel_and_no_count(hip, name):
+    """k_primary deals the samples of an 8x8 pixel block to wavefronts as one offset of 64 pixels, or as 2 .. 64 offsets of fewer
+    pixels (option wave_samples; by scene when 0).  Only the dealing changes - a sample's ray, its random streams and its place
+    in the colour planes are the same - so the frame and every count are identical, with sample counts that have a power of two
+    in them (12 = 4 x 3, 16) and without (3, 1), on whole frames and on tiles."""
+    p = _load(name)
+    p.lower(hip)
+    w, h = 192, 128
+    tiles = [(0, 0, 64, 64), (64, 32, 128, 96)]
+    try:
+        for spp in (1, 3, 12, 16):
+            jit = ft.jitter_pattern(spp)
+            ref = ref_t = None
+            for g in (1, 0, 2, 4, 16, 64):
+                hip.set_option("wave_samples", g)
+                img, st = hip.render(p.camera, w, h, spp, jit)
+                img_t, st_t = hip.render(p.camera, w, h, spp, jit, tiles=tiles)
+                if ref is None:
+                    ref, ref_t = (img, st), (img_t, st_t)
+                    continue
+                assert np.array_equal(img, ref[0]) and np.array_equal(img_t, ref_t[0]), (spp, g)
+                for key in ("rays_shadow", "rays_reflect", "rays_traced", "hits_total", "rays_reference_equivalent"):
+                    assert st[key] == ref[1][key] and st_t[key] == ref_t[1][key], (spp, g, key)
+    finally:
+        hip.set_option("wave_samples", 0)
+    with pytest.raises(Exception):
+        hip.set_option("wave_samples", 3)
+
+
 @pytest.mark.parametrize("name", ["bunny", "moon", "hollow-sphere", "bunny-bsp12", "sample-det"])
 def test_pixel_block_classification_changes_no_pixel(hip, name):
     """k_classify finishes 64-pixel blocks that cannot see any object before a single ray is generated: the frame, the hit
