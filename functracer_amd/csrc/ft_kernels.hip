@@ -269,6 +269,33 @@ FT_DEV bool tri_hit(cdp T, const Ray& r, double& t_out) {
     return false;
 }
 
+// tri_hit for the packet walk: the same products and the same comparisons, with wave-uniform exits in place of eight per-lane
+// ones.  A lane's early return saves nothing while another lane of the wave goes on, and each one is a saved and restored exec mask:
+// the rejections before the division are gathered into one flag (nothing passes them: the 64 lanes skip the division), the ones
+// after it into a second.  Lanes that have failed carry on with values nobody reads (1 / 0 included: no traps on the device).
+FT_DEV bool tri_hit_wave(cdp T, const Ray& r, bool live, double& t_out) {
+    const double v0x = T[0], v0y = T[1], v0z = T[2], e1x = T[3], e1y = T[4], e1z = T[5], e2x = T[6], e2y = T[7], e2z = T[8];
+    const double hx = r.dy * e2z - r.dz * e2y, hy = e2x * r.dz - e2z * r.dx, hz = r.dx * e2y - r.dy * e2x;
+    const double a = e1x * hx + e1y * hy + e1z * hz;
+    const double sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
+    const double sh = sx * hx + sy * hy + sz * hz;
+    const double abs_a = fabs(a), lim = abs_a * 1.000000000000004;
+    const bool pos = a > 0.0, neg = a < 0.0;
+    bool ok = live & !((a > -kEps) & (a < kEps));
+    ok = ok & !(((sh < 0.0) & pos) | ((sh > 0.0) & neg) | (fabs(sh) > lim));
+    if (!__any(ok)) return false;                                   // the usual end in a dense mesh: the triangle lies beside the whole bundle
+    const double qx = sy * e1z - sz * e1y, qy = e1x * sz - e1z * sx, qz = sx * e1y - sy * e1x;
+    const double dq = r.dx * qx + r.dy * qy + r.dz * qz;
+    ok = ok & !(((dq < 0.0) & pos) | ((dq > 0.0) & neg) | (fabs(dq) > lim));
+    if (!__any(ok)) return false;
+    const double f = 1.0 / a;
+    const double u = f * sh;
+    const double v = f * dq;
+    const double t = f * (e2x * qx + e2y * qy + e2z * qz);
+    t_out = t;
+    return ok & !((u < 0.0) | (u > 1.0)) & !((v < 0.0) | (u + v > 1.0)) & (t > kEps);
+}
+
 // BoundingBox.intersects (BoundingBox.fs:32-58), inverse direction precomputed per ray.
 FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz, double* entry = nullptr) {
     struct { double bmin[3], bmax[3]; } n = {{nd[0], nd[1], nd[2]}, {nd[3], nd[4], nd[5]}};
@@ -638,13 +665,15 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
         } else {
             const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
             for (uint32_t k = 0; k < count; ++k) {                 // wave-uniform: scalar loads
-                double t;
-                if (alive && tri_hit(S.tris + 9ull * (first + k), r, t)) {
-                    if (ANY) { if (t < bound) { q.blocked = true; alive = false; reach = -__builtin_inf(); } }
-                    else {
-                        const uint32_t orig = S.tri_orig[first + k];
-                        if (t < bound || (found && t == bound && orig < best_tri)) { bound = t; reach = t; best_tri = orig; found = true; }
-                    }
+                double t = 0.0;
+                const bool h = tri_hit_wave(S.tris + 9ull * (first + k), r, alive, t);
+                if (ANY) {
+                    const bool b = h & (t < bound);
+                    q.blocked = q.blocked | b; alive = alive & !b; reach = b ? -__builtin_inf() : reach;
+                } else if (__any(h)) {                              // a live lane's reach IS its nearest distance so far
+                    const uint32_t orig = S.tri_orig[first + k];
+                    const bool nearer = h & ((t < reach) | (found & (t == reach) & (orig < best_tri)));
+                    reach = nearer ? t : reach; best_tri = nearer ? orig : best_tri; found = found | nearer;
                 }
             }
             if (ANY) { if (!__any(alive)) break; }
@@ -653,7 +682,7 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
         --sp;
         cur = __builtin_amdgcn_readlane(stack_lanes, sp);
     }
-    if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
+    if (!ANY && found) q.hit(reach, leaf, best_tri, lit);
 }
 
 // ---------------------------------------------------------------------------------------------
