@@ -30,8 +30,7 @@ struct DeviceBuf {
 // Stage indices of ft_get_kernel_times.
 enum { kStageOther = 0, kStageClosest = 1, kStageShade = 2, kStageResolve = 3, kStagePrimary = 4, kStages = 5 };
 // What a frame copies back when it retires: FrameCounters from `stats` to its end.
-struct FrameTail { ftk::RenderCounters stats[ftk::kStatStripes]; ftk::PixCount counts; uint32_t classify_ticket, classify_error, pad[2]; };
-static_assert(sizeof(FrameTail) == sizeof(ftk::FrameCounters) - offsetof(ftk::FrameCounters, stats), "FrameTail mirrors the end of FrameCounters");
+static_assert(sizeof(ftk::FrameCounters) % 16 == 0 && offsetof(ftk::RenderCounters, ref_equiv) == 32, "the hand-over at the end of a frame copies words and clears 16 bytes at a time");
 
 struct ft_context {
     std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
@@ -59,6 +58,7 @@ struct ft_context {
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
     DeviceBuf d_rays[2], d_acc, d_out, d_out8, d_pixels, d_jitter, d_fc, d_dbg_in, d_dbg_out;
+    bool fc_clean = false;          // d_fc is all zero: the previous frame's last kernel cleared it behind its report (no fill needed)
     uint32_t classify_epoch = 0;    // tags the entries k_classify's waves publish in d_wave_counts (cleared only when it wraps or the buffer grows)
     int64_t ray_capacity = 0, acc_capacity = 0;
     // Per-frame host state.  Two slots, so that one frame can be queued while the previous one still runs (ft_render_enqueue).
@@ -67,8 +67,8 @@ struct ft_context {
         struct Span { hipEvent_t a, b; int kind; };
         std::vector<Span> spans;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
-        FrameTail* h_tail = nullptr;            // pinned landing place of the frame's statistic stripes and k_classify's error word
-        uint32_t* h_rays = nullptr;             // ... and of the last chunk's rays per bounce (ChunkCounters::n_rays)
+        ftk::FrameReport* h_report = nullptr;   // pinned: the frame's statistic stripes, k_classify's error word and the last chunk's rays per bounce,
+        ftk::FrameReport* d_report = nullptr;   // written by the frame's last kernel through this device-side address of the same memory
         int levels_launched = 0, last_bounce = 0;
         uint64_t signature = 0;                 // what the frame rendered (scene, size, samples, depth, threshold): keys the staged-launch hint
         bool pending = false;
@@ -251,7 +251,7 @@ void ft_destroy(ft_context* c) {
                              &c->d_rays[0], &c->d_rays[1], &c->d_acc, &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc,
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
-        for (auto& f : c->slots) { if (f.h_tail) { (void)hipHostFree(f.h_tail); f.h_tail = nullptr; } if (f.h_rays) { (void)hipHostFree(f.h_rays); f.h_rays = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
+        for (auto& f : c->slots) { if (f.h_report) { (void)hipHostFree(f.h_report); f.h_report = nullptr; f.d_report = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -439,6 +439,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_coarse, f.coarse_boxes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
     if ((rc = ensure(c, c->d_fc, sizeof(ftk::FrameCounters))) != FT_OK) return rc;
+    c->fc_clean = false;
     FT_HIP(c, hipStreamSynchronize(c->stream));
     {   // the BVHs the flattener left to the device (ft_bvh.hip), straight into the ranges reserved in the arrays just uploaded
         const auto t0 = std::chrono::steady_clock::now();
@@ -775,7 +776,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         cls = ftk::ClassifyOut{c->d_block_pos.as<int32_t>(), c->d_pos_block.as<uint32_t>(), c->d_wave_counts.as<uint32_t>()};
     }
     auto* fc = c->d_fc.as<ftk::FrameCounters>();
-    FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream));   // the ONE fill of a frame: chunk counters, statistic stripes, list length, ticket
+    // chunk counters, statistic stripes, list length, tickets: cleared by the previous frame's last kernel, or by a fill when there was none
+    if (!c->fc_clean) FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream));
+    c->fc_clean = false;                                           // until this frame's own hand-over is queued
 
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
@@ -833,6 +836,10 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         timed(kStageOther, [&] { ftk::launch_classify(Lg, c->dev_scene, all, cls, jitter_extent, epoch, fc); });
         ++n_launches;
     }
+    if (!F.h_report) {
+        FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_report), sizeof(ftk::FrameReport), hipHostMallocDefault));
+        FT_HIP(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&F.d_report), F.h_report, 0));
+    }
     double* const out_rgb = q.format == 1 ? nullptr : c->d_out.as<double>();
     uint8_t* const out_rgba = q.format == 1 ? c->d_out8.as<uint8_t>() : nullptr;
     for (const Job& job : jobs) {
@@ -861,23 +868,21 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         else if (n_levels >= 1) timed(kStageShade, [&] { bounces([](int, auto&& fn) { fn(); }); });
         if (corner) timed(kStageResolve, [&] { ftk::launch_resolve_corner(Lg, c->d_acc.as<double>(), n_samples, job.w, job.h, c->d_out_index.as<uint32_t>() + job.out_base, out_rgb, out_rgba); });
         else {
+            const bool last_job = &job == &jobs.back();            // the frame's last kernel hands the counters over (FrameReport)
             ftk::ResolveArgs ra{c->d_acc.as<double>(), n_samples, classify ? &fc->counts : nullptr, job.id_base, n_pix, spp,
                                 classify ? c->d_pos_block.as<uint32_t>() : nullptr, (classify && n_chunks == 1) ? c->d_block_pos.as<int32_t>() : nullptr,
-                                (uint32_t)(n_pix_total / 64), c->d_pixels.as<uint32_t>(), out_rgb, out_rgba};
+                                (uint32_t)(n_pix_total / 64), c->d_pixels.as<uint32_t>(), out_rgb, out_rgba, fc, last_job ? F.d_report : nullptr};
             timed(kStageResolve, [&] { ftk::launch_resolve(Lg, ra); });
+            if (last_job) c->fc_clean = true;
         }
         ++n_launches;
     }
+    if (!c->fc_clean) { ftk::launch_report(Lg, fc, F.d_report); c->fc_clean = true; }   // corner frames end in k_resolve_corner: the hand-over is a launch of its own
     if (boundary_fresh) ev1 = boundary;
     else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
     FT_HIP(c, hipGetLastError());
-    if (!F.h_tail) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_tail), sizeof(FrameTail), hipHostMallocDefault));
-    FT_HIP(c, hipMemcpyAsync(F.h_tail, &fc->stats[0], sizeof(FrameTail), hipMemcpyDeviceToHost, c->stream));   // rides the frame's one wait
-    if (!F.h_rays) FT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&F.h_rays), sizeof(fc->cc.n_rays), hipHostMallocDefault));
-    FT_HIP(c, hipMemcpyAsync(F.h_rays, &fc->cc.n_rays[0], sizeof(fc->cc.n_rays), hipMemcpyDeviceToHost, c->stream));
     F.signature = signature; F.levels_launched = levels_launched; F.last_bounce = last_bounce;
-    F.done = next_event(F);
-    if (F.done) FT_HIP(c, hipEventRecord(F.done, c->stream));
+    F.done = ev1;                                                  // nothing follows the last kernel: its end is the frame's
     F.ev0 = ev0; F.ev1 = ev1; F.pending = true; F.wall0 = wall0; F.timing = timing;
     F.rays_primary = 0; for (auto& j : jobs) F.rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;
     F.n_pix_total = n_pix_total; F.spp = spp; F.n_launches = n_launches; F.n_chunks = n_chunks; F.classify = classify; F.format = q.format;
@@ -896,18 +901,12 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
     if (!F.pending) return FT_OK;
     F.pending = false;
     if (F.done) FT_HIP(c, hipEventSynchronize(F.done)); else FT_HIP(c, hipStreamSynchronize(c->stream));
-    ftk::RenderCounters hrc{};                                      // the stripes, summed
-    for (int k = 0; k < ftk::kStatStripes; ++k) {
-        const ftk::RenderCounters& s = F.h_tail->stats[k];
-        hrc.rays_shadow += s.rays_shadow; hrc.rays_reflect += s.rays_reflect; hrc.hits_primary += s.hits_primary; hrc.csg_overflow += s.csg_overflow;
-        hrc.ref_equiv += s.ref_equiv; hrc.hits_total += s.hits_total;
-        hrc.pixels_culled += s.pixels_culled; hrc.rays_shadow_primary += s.rays_shadow_primary; hrc.rays_reflect_primary += s.rays_reflect_primary;
-    }
-    const bool classify_failed = F.h_tail->classify_error != 0;
+    const ftk::RenderCounters hrc = F.h_report->total;              // the stripes, summed by the frame's last kernel
+    const bool classify_failed = F.h_report->classify_error != 0;
     // How deep this frame's rays went: the next frame of the same signature launches that many levels + 1 (a level that followed its
     // rays in registers does not say how deep they went: then the hint keeps every level it launched).
     int deepest = 0;
-    while (deepest + 1 <= ftk::kMaxBounce && F.h_rays[deepest + 1] > 0) ++deepest;
+    while (deepest + 1 <= ftk::kMaxBounce && F.h_report->n_rays[deepest + 1] > 0) ++deepest;
     if (F.levels_launched < F.last_bounce && deepest >= F.levels_launched) deepest = F.last_bounce;   // the followed level had rays: look again with every level next time
     c->staged_hint = deepest; c->staged_signature = F.signature;
     const int timing = F.timing; const int32_t spp = F.spp; const int64_t n_pix_total = F.n_pix_total; const bool classify = F.classify;
@@ -1030,6 +1029,7 @@ static int32_t debug_closest(ft_context* c, const double* origins, const double*
     double* din = c->d_dbg_in.as<double>();
     FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
+    c->fc_clean = false;
     FT_HIP(c, hipMemsetAsync(c->d_fc.p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
     double* dt = c->d_dbg_out.as<double>();
     double* dp = dt + N; double* dn = dp + 3 * N; double* dc = dn + 3 * N;
@@ -1069,6 +1069,7 @@ static int32_t debug_blocked(ft_context* c, const double* origins, const double*
     FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 6 * N, max_dist, N * 8, hipMemcpyHostToDevice, c->stream));
+    c->fc_clean = false;
     FT_HIP(c, hipMemsetAsync(c->d_fc.p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
     const size_t lds = lds_bytes_for(c->flat);
     ftk::Launch L{c->stream, c->n_cu * 4, lds, 0};
@@ -1108,6 +1109,7 @@ static int32_t debug_colour(ft_context* c, const double* origins, const double* 
         soa[6 * N + i] = 1.0; slot[i] = (uint32_t)i;
     }
     auto* fc = c->d_fc.as<ftk::FrameCounters>();
+    c->fc_clean = false;
     FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream));
     const ftk::RayBuf rb0 = ray_view(c->d_rays[0], c->ray_capacity), rb1 = ray_view(c->d_rays[1], c->ray_capacity);
     for (int k = 0; k < 7; ++k) FT_HIP(c, hipMemcpyAsync(c->d_rays[0].as<double>() + (size_t)k * cap, soa.data() + (size_t)k * N, N * 8, hipMemcpyHostToDevice, c->stream));
@@ -1127,7 +1129,7 @@ static int32_t debug_colour(ft_context* c, const double* origins, const double* 
     FT_HIP(c, hipGetLastError());
     std::vector<double> planes(3 * N);
     FT_HIP(c, hipMemcpyAsync(planes.data(), c->d_acc.p, 3 * N * 8, hipMemcpyDeviceToHost, c->stream));
-    FrameTail tail;
+    struct { ftk::RenderCounters stats[ftk::kStatStripes]; } tail;
     FT_HIP(c, hipMemcpyAsync(&tail, &fc->stats[0], sizeof tail, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < N; ++i) { rgb[3 * i] = planes[i]; rgb[3 * i + 1] = planes[N + i]; rgb[3 * i + 2] = planes[2 * N + i]; }

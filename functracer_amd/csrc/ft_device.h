@@ -80,8 +80,21 @@ struct FrameCounters {
     PixCount counts;
     uint32_t classify_ticket;      // k_classify: waves take their 64-block segment in ticket order, so a wave's predecessors are always running
     uint32_t classify_error;       // set when a bounded wait ran out (never observed; the host then fails the frame instead of hanging)
-    uint32_t pad[2];
+    uint32_t report_ticket;        // k_resolve / k_report: ticket stripes that are complete (the workgroup that completes the last one writes the frame's report)
+    uint32_t pad[1];
+    uint32_t report_stripe[64];    // workgroups of stripe blockIdx % 64 that have finished (8000 tickets on one word took 80 us)
 };
+// What the host reads of a frame's counters, in pinned host memory.  The last workgroup of the frame's last k_resolve writes it and
+// then clears the FrameCounters for the next frame: a steady stream of frames needs no fill and no device-to-host copy in between
+// (three dispatches less per frame, ~20 us of a 0.4 ms frame with the gaps around them).
+struct FrameReport {               // 256 bytes: one wavefront writes it with one store instruction (word by word over PCIe a report of
+    RenderCounters total;          // all 64 stripes took 200 us); the stripes summed in stripe order
+    uint32_t n_rays[kMaxBounce + 2];   // the last chunk's rays per bounce
+    uint32_t n_pix_active;         // PixCount::n_pix
+    uint32_t classify_error;
+    uint32_t pad[12];
+};
+static_assert(sizeof(FrameReport) == 256, "FrameReport is written as 64 words");
 
 struct Camera {                    // ImagePlane (Image.fs:55-63), computed on the host
     double o[3], k[3], i[3], j[3];
@@ -138,8 +151,10 @@ struct ResolveArgs {
     uint32_t n_blocks_total;
     const uint32_t* pixel_ids;     // the original pixel list (whole frame: out index = pixel id); null: out index = list position
     double* out_rgb; uint8_t* out_rgba;
+    FrameCounters* fc; FrameReport* report;   // report non-null: the frame's last launch (see FrameReport; fc is cleared behind it)
 };
 void launch_resolve(const Launch& L, const ResolveArgs& a);
+void launch_report(const Launch& L, FrameCounters* fc, FrameReport* report);   // the same hand-over as a launch of its own (frames that end in another kernel)
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
 void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba);
 // Device-side BVH build (ft_bvh.hip): a linear BVH over triangles [first_global, first_global + n) of `tris`, written into the ranges

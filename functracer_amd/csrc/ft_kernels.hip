@@ -1822,6 +1822,51 @@ FT_DEV void write_pixel(double* out_rgb, uint8_t* out_rgba, size_t o, double r, 
 // divided once (JitteredSampling.blendPixels, Image.fs:112-116: Array.average = sum, then DivideByInt, CommonTypes.fs:43-48); with
 // block_pos the launch also writes Colour.Zero for the pixels of every block k_classify finished.  Each pixel of the frame is
 // written once, as FP64 RGB and / or as RGBA8 bytes.
+// The end of a frame: the last workgroup to get here copies what the host wants of the counters into the pinned report and clears
+// the counters for the next frame.  Every other workgroup has finished with them (the ticket is taken after a workgroup's last
+// access) and the kernels that wrote them ended before this one began.
+FT_DEV void hand_over_frame(FrameCounters* fc, FrameReport* report) {
+    __shared__ uint32_t last;
+    __shared__ unsigned long long cells[kStatStripes * 16];
+    const uint32_t t = threadIdx.x;
+    __syncthreads();
+    // no fence: what is handed over was written by earlier kernels, and this workgroup's own reads of the counters returned long ago
+    // (a __threadfence here is an L2 write-back per workgroup: it made k_resolve take 314 us instead of 18)
+    if (t == 0) {
+        const uint32_t stripe = blockIdx.x & 63u, in_stripe = (gridDim.x - stripe + 63u) / 64u, n_stripes = gridDim.x < 64u ? gridDim.x : 64u;
+        last = 0u;
+        if (atomicAdd(&fc->report_stripe[stripe], 1u) == in_stripe - 1u) last = atomicAdd(&fc->report_ticket, 1u) == n_stripes - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    static_assert(sizeof(RenderCounters) == 128 && kStatStripes * 16 == 4 * kBlock, "the stripes are read as 4 x 256 eight-byte cells");
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&fc->stats[0]);
+    for (uint32_t k = 0; k < 4; ++k) cells[k * kBlock + t] = src[k * kBlock + t];           // all loads in flight at once
+    unsigned long long* rep = cells;                                // the report is assembled over the cells once they are summed
+    __syncthreads();
+    unsigned long long sum = 0ull;
+    if (t < 16) {                                                   // one 8-byte field of RenderCounters per thread, summed over the stripes in order
+        if (t == 4) { double s = 0.0; for (int k = 0; k < kStatStripes; ++k) s += __longlong_as_double((long long)cells[16 * k + 4]); sum = (unsigned long long)__double_as_longlong(s); }
+        else for (int k = 0; k < kStatStripes; ++k) sum += cells[16 * k + t];
+    }
+    uint32_t word = 0u;
+    if (t >= 64 && t < 64 + kMaxBounce + 2) word = fc->cc.n_rays[t - 64];
+    else if (t == 128) word = fc->counts.n_pix;
+    else if (t == 129) word = fc->classify_error;
+    __syncthreads();
+    uint32_t* words = reinterpret_cast<uint32_t*>(rep);
+    if (t < 16) rep[t] = sum;
+    else if (t >= 64 && t < 64 + kMaxBounce + 2) words[32 + (t - 64)] = word;
+    else if (t == 128 || t == 129) words[32 + kMaxBounce + 2 + (t - 128)] = word;
+    else if (t >= 130 && t < 142) words[34 + kMaxBounce + 2 + (t - 130)] = 0u;
+    __syncthreads();
+    if (t < 64) reinterpret_cast<uint32_t*>(report)[t] = words[t];
+    __syncthreads();
+    uint4* z = reinterpret_cast<uint4*>(fc);
+    for (uint32_t w = threadIdx.x; w < sizeof(FrameCounters) / 16; w += kBlock) z[w] = uint4{0u, 0u, 0u, 0u};
+}
+__global__ __launch_bounds__(kBlock) void k_report(FrameCounters* fc, FrameReport* report) { hand_over_frame(fc, report); }
+
 __global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs a) {
     uint32_t n_pix = a.n_pix_host;                                  // all pixels of the chunk, or its window of the frame's active list (k_classify)
     if (a.counts) { const uint32_t n_active = a.counts->n_pix; n_pix = n_active > a.first ? (n_active - a.first < a.n_pix_host ? n_active - a.first : a.n_pix_host) : 0u; }
@@ -1844,6 +1889,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs a) {
             write_pixel(a.out_rgb, a.out_rgba, a.pixel_ids ? (size_t)a.pixel_ids[p] : (size_t)p, 0.0, 0.0, 0.0);
         }
     }
+    if (a.report) hand_over_frame(a.fc, a.report);
 }
 
 __global__ __launch_bounds__(kBlock) void k_resolve_corner(const double* __restrict__ acc, uint32_t acc_stride, uint32_t w, uint32_t h,
@@ -1952,8 +1998,9 @@ void launch_bounce(const Launch& L, const DevScene& S, const Primary& gen, RayBu
 }
 void launch_resolve(const Launch& L, const ResolveArgs& a) {
     const uint32_t work = a.block_pos ? (a.n_blocks_total * 64u > a.n_pix_host ? a.n_blocks_total * 64u : a.n_pix_host) : a.n_pix_host;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, L.grid * 4)), dim3(kBlock), 0, L.stream, a);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, L.grid)), dim3(kBlock), 0, L.stream, a);
 }
+void launch_report(const Launch& L, FrameCounters* fc, FrameReport* report) { hipLaunchKernelGGL(k_report, dim3(1), dim3(kBlock), 0, L.stream, fc, report); }
 void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba) {
     hipLaunchKernelGGL(k_resolve_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, w, h, out_index, out_rgb, out_rgba);
 }
