@@ -786,11 +786,15 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;   // FANCY
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
     if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
-    // Samples per bounce-0 wavefront (k_primary).  Measured at 1080p x 16: narrow bundles of 4 pixels x 16 samples pay where a wave walks
-    // a BVH (bunny through BSP leaves 1.46 -> 1.29 ms, bunny 0.363 -> 0.358); elsewhere their scattered 32-byte colour stores cost more
-    // than the narrower bundle saves (moon 1.28 -> 1.35 ms) and 16 pixels x 4 samples (whole 128-byte lines) is the better deal
-    // (night-house 4.63 -> 4.47 ms, moon 1.29).
-    c->dev_scene.wave_samples_log2 = c->wave_samples_log2 >= 0 ? c->wave_samples_log2 : ((variant & 4) ? 4 : 2);
+    // Samples per bounce-0 wavefront (slot_at, ft_kernels.hip): 2^group_log2 samples of 64 / 2^group_log2 pixels when the sample count
+    // has that power of two in it and the list is made of whole 8x8 blocks.  Narrow bundles pay most where a wave walks a BVH
+    // (measured at 1080p x 16, 1 -> 16 samples per wave: bunny through BSP leaves 1.46 -> 1.29 ms, night-house 4.63 -> 4.45).
+    int group_log2 = 0;
+    {
+        const int cap = c->wave_samples_log2 >= 0 ? c->wave_samples_log2 : 4;
+        while (group_log2 < cap && !((spp >> group_log2) & 1)) ++group_log2;
+        if (corner || !c->pixels_tiled) group_log2 = 0;
+    }
     int variant_p = variant;
     const int blocks_p = ftk::occupancy_blocks_primary(lds, &variant_p);
     ftk::Launch Lp{c->stream, c->n_cu * blocks_p, lds, variant_p};
@@ -851,6 +855,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
                          (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
                          1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h), nullptr, nullptr};
         if (classify) { gen.counts = &fc->counts; gen.block_map = c->d_pos_block.as<uint32_t>(); }   // pix_base = job.id_base: the window's start in the active list
+        gen.group_log2 = (n_pix % 64u == 0u) ? group_log2 : 0;
         timed(kStagePrimary, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], c->d_acc.as<double>(), n_samples, max_depth, fc); });
         ++n_launches;
         // Bounces >= 1: one k_bounce per level of the reflection tree, as many as the previous frame of this signature had (+ 1).
@@ -871,7 +876,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
             const bool last_job = &job == &jobs.back();            // the frame's last kernel hands the counters over (FrameReport)
             ftk::ResolveArgs ra{c->d_acc.as<double>(), n_samples, classify ? &fc->counts : nullptr, job.id_base, n_pix, spp,
                                 classify ? c->d_pos_block.as<uint32_t>() : nullptr, (classify && n_chunks == 1) ? c->d_block_pos.as<int32_t>() : nullptr,
-                                (uint32_t)(n_pix_total / 64), c->d_pixels.as<uint32_t>(), out_rgb, out_rgba, fc, last_job ? F.d_report : nullptr};
+                                (uint32_t)(n_pix_total / 64), c->d_pixels.as<uint32_t>(), out_rgb, out_rgba, (uint32_t)gen.group_log2, fc, last_job ? F.d_report : nullptr};
             timed(kStageResolve, [&] { ftk::launch_resolve(Lg, ra); });
             if (last_job) c->fc_clean = true;
         }

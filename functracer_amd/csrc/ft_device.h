@@ -38,7 +38,6 @@ struct DevScene {
     int32_t n_items, n_cull_rows;  // n_cull_rows < 0: pre-test disabled
     int32_t csg_rows, lane_fold;   // LDS rows per hit-list column and lanes folded together (see HitList): csg_cap <= csg_rows * lane_fold
     int32_t n_simd;                // SIMDs of the device (CUs x 4): how far few rays are spread (batch_lanes_for)
-    int32_t wave_samples_log2;     // a bounce-0 wavefront takes up to 2^this samples of 64 / 2^this pixels (k_primary), 0: one sample of 64 pixels
     int32_t coherent_waves;        // 1 (default): bounce-0 wavefronts use the bundle paths (cone cull, packet traversal); 0: every wave is treated as incoherent (diagnostic)   // sum over lights of the shadow rays the reference casts per hit
 };
 
@@ -124,6 +123,7 @@ struct Primary {
     const PixCount* counts;        // non-null: the chunk's list is the FRAME's active pixel list (k_classify), counts->n_pix its length, and this
                                    // chunk works on the window [pix_base, pix_base + n_pix) of it
     const uint32_t* block_map;     // with counts: block b of the active list is block block_map[b] of pixel_ids; null: pixel_ids is the list itself
+    int32_t group_log2;            // samples are numbered in groups of 2^this per 64-pixel block (slot_at, ft_kernels.hip); 0: sample plane by sample plane
 };
 // Bounce 0 fused (k_primary): generate the primary rays of the chunk, closest hit, shadow queries, shaders, reflection spawn, and
 // one colour per sample stored into acc (Colour.Zero for a miss).
@@ -151,6 +151,7 @@ struct ResolveArgs {
     uint32_t n_blocks_total;
     const uint32_t* pixel_ids;     // the original pixel list (whole frame: out index = pixel id); null: out index = list position
     double* out_rgb; uint8_t* out_rgba;
+    uint32_t group_log2;           // the chunk's slot numbering (Primary::group_log2)
     FrameCounters* fc; FrameReport* report;   // report non-null: the frame's last launch (see FrameReport; fc is cleared behind it)
 };
 void launch_resolve(const Launch& L, const ResolveArgs& a);

@@ -1165,16 +1165,41 @@ struct JitterFrame {
 // and quotient * b < 2^32 (four FP64 instructions in place of the ~25 of an integer division).
 FT_DEV uint32_t div_by(uint32_t a, double inv_b) { return (uint32_t)(((double)a + 0.5) * inv_b); }
 
-// Pixels per sample plane of the chunk: the active count written by k_classify, or the host's when nothing was classified.
-struct Pix { uint32_t n; double inv; };
+// Pixels per sample plane of the chunk: the active count written by k_classify, or the host's when nothing was classified; and how
+// the chunk's samples are numbered (see slot_at).
+struct Pix { uint32_t n; double inv; uint32_t n_blocks; double inv_blocks; uint32_t group_log2; };
 FT_DEV Pix pix_count(PrimaryArg g) {
     const PixCount* c = g->counts;
+    uint32_t n = g->n_pix;
     if (c) {                                                        // this chunk's window [pix_base, pix_base + n_pix) of the frame's active list
         const uint32_t n_active = to_const_as(c)->n_pix, first = g->pix_base, cap = g->n_pix;
-        const uint32_t n = n_active > first ? (n_active - first < cap ? n_active - first : cap) : 0u;
-        return {n, 1.0 / (double)n};                                // one division per batch is cheaper than a launch that stores the reciprocal
+        n = n_active > first ? (n_active - first < cap ? n_active - first : cap) : 0u;
     }
-    return {g->n_pix, g->inv_n_pix};
+    const uint32_t nb = n >> 6;                                     // one division per batch is cheaper than a launch that stores the reciprocals
+    return {n, 1.0 / (double)n, nb, 1.0 / (double)(nb ? nb : 1u), (n & 63u) ? 0u : (uint32_t)g->group_log2};   // grouped numbering needs whole blocks (k_resolve: the same rule)
+}
+
+// How a chunk's samples are numbered.  A slot is a sample's place in the colour planes (acc) and the unit a wavefront's lane takes.
+// Plain numbering (group_log2 = 0): slot = s * n_pix + pixel, sample plane by sample plane, so 64 consecutive slots are one 8x8 pixel
+// block under one jitter offset.  Grouped numbering (G = 2^group_log2 divides the sample count, the list is made of whole blocks):
+// the G x 64 samples of one block under G consecutive offsets are dealt out the other way round - 64 consecutive slots are 64 / G of
+// the block's pixels under all G offsets, a bundle 1 / G as wide on the image plane, which enters fewer BVH nodes and passes fewer
+// cull tests per ray.  Either way a wavefront's 64 slots are 512 contiguous bytes of each colour plane.
+//   batch b = slot / 64 = (s0 + k) * n_blocks + blk,  lane = slot % 64 = (s - s0) * (64 / G) + j
+//   for sample s = s0 + (s - s0) with s0 a multiple of G, pixel = blk * 64 + k * (64 / G) + j of the list
+struct SlotAt { uint32_t s, pl; };
+FT_DEV SlotAt slot_at(const Pix& px, uint32_t batch, uint32_t lane) {          // grouped numbering only
+    const uint32_t sb = div_by(batch, px.inv_blocks), blk = batch - sb * px.n_blocks, k = sb & ((1u << px.group_log2) - 1u), pw = 6u - px.group_log2;
+    return {(sb - k) + (lane >> pw), (blk << 6) + (k << pw) + (lane & ((1u << pw) - 1u))};
+}
+FT_DEV SlotAt slot_at(const Pix& px, uint32_t slot) {
+    if (px.group_log2 == 0u) { const uint32_t s = div_by(slot, px.inv); return {s, slot - s * px.n}; }
+    return slot_at(px, slot >> 6, slot & 63u);
+}
+FT_DEV uint32_t slot_of(uint32_t n_pix, uint32_t n_blocks, uint32_t group_log2, uint32_t s, uint32_t pl) {
+    if (group_log2 == 0u) return s * n_pix + pl;
+    const uint32_t g1 = (1u << group_log2) - 1u, pw = 6u - group_log2, w = pl & 63u;
+    return ((((s & ~g1) + (w >> pw)) * n_blocks + (pl >> 6)) << 6) + (((s & g1) << pw) | (w & ((1u << pw) - 1u)));
 }
 
 // Pixel id behind entry `at` of the chunk's list.  In a classified frame the list is the frame's ACTIVE list, kept as a map from
@@ -1184,20 +1209,14 @@ FT_DEV uint32_t list_pixel(PrimaryArg g, uint32_t at) {
     return g->pixel_ids[map ? map[at >> 6] * 64u + (at & 63u) : at];
 }
 FT_DEV unsigned long long sample_id(PrimaryArg g, const Pix& px, uint32_t slot) {
-    const uint32_t s = div_by(slot, px.inv), pl = slot - s * px.n;
-    const uint32_t pid = g->pixel_ids ? list_pixel(g, g->pix_base + pl) : pl;   // no pixel list: the slot is the sample (ft_debug_colour)
-    return (unsigned long long)pid * (unsigned long long)g->spp + s;
+    const SlotAt at = slot_at(px, slot);
+    const uint32_t pid = g->pixel_ids ? list_pixel(g, g->pix_base + at.pl) : at.pl;   // no pixel list: the slot is the sample (ft_debug_colour)
+    return (unsigned long long)pid * (unsigned long long)g->spp + at.s;
 }
 
-// Primary rays are never stored: k_primary generates them from the sample index
-// (ImagePlane.rayThroughPixel, Image.fs:83-89; slot = s*n_pix + pixel, so the 64 lanes of a wave are the
-// 64 pixels of one 8x8 block for one jitter offset).
-FT_DEV uint32_t primary_pixel(PrimaryArg g, const Pix& px, uint32_t i) {   // the one memory access a primary ray needs
-    const uint32_t s = div_by(i, px.inv), pl = i - s * px.n;
-    return list_pixel(g, g->pix_base + pl);
-}
-FT_DEV Ray primary_ray_from(PrimaryArg g, const Pix& count, uint32_t i, uint32_t pid) {
-    const uint32_t s = div_by(i, count.inv);
+// Primary rays are never stored: k_primary generates them from the sample's place (ImagePlane.rayThroughPixel, Image.fs:83-89).
+FT_DEV uint32_t primary_pixel(PrimaryArg g, const SlotAt& at) { return list_pixel(g, g->pix_base + at.pl); }   // the one memory access a primary ray needs
+FT_DEV Ray primary_ray_from(PrimaryArg g, uint32_t s, uint32_t pid) {
     const uint32_t py = div_by(pid, g->inv_stride), px = pid - py * g->stride;
     const double centre_x = g->cam.tlx + (double)px * g->cam.pw, centre_y = g->cam.tly - (double)py * g->cam.ph;
     const double ox = g->jitter[2 * s], oy = g->jitter[2 * s + 1];
@@ -1375,39 +1394,26 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
     const uint32_t n = n_pix * (uint32_t)K->gen.spp;
     const int n_lights = S.n_lights;
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
-    const uint32_t B = batch_lanes_for(n, S.lane_fold, S.n_simd);
+    // grouped numbering (slot_at): whole wavefronts; plain: few rays are spread over the SIMDs
+    const uint32_t B = px.group_log2 ? 64u : batch_lanes_for(n, S.lane_fold, S.n_simd);
     const uint32_t n_batches = (n + B - 1) / B;
-    const bool whole_blocks = B == 64u && (n_pix & 63u) == 0u;
     const bool coherent = K->S.coherent_waves != 0;
-    // Which 64 samples a wavefront takes.  Slots are numbered sample plane by sample plane (s * n_pix + pixel) and a batch of 64
-    // consecutive ones is one 8x8 pixel block under one jitter offset.  When the sample count has a power of two G in it, the G
-    // batches of one block under G consecutive offsets are dealt out the other way round: each takes 64 / G of the block's pixels
-    // under all G offsets - a bundle 1 / G as wide on the image plane, which enters fewer BVH nodes and passes fewer cull tests
-    // per ray.  Only the dealing changes: a slot's ray, its random streams and its place in acc are the same.
-    uint32_t group_log2 = 0;
-    if (whole_blocks) { const uint32_t spp = (uint32_t)K->gen.spp, cap = (uint32_t)K->S.wave_samples_log2; while (group_log2 < cap && !((spp >> group_log2) & 1u)) ++group_log2; }
-    const uint32_t n_blocks = n_pix >> 6;
-    const double inv_blocks = 1.0 / (double)(n_blocks ? n_blocks : 1u);
-    auto slot_of = [&](uint32_t batch) -> uint32_t {
-        if (group_log2 == 0) return batch * B + lane_id();
-        const uint32_t s = div_by(batch, inv_blocks), blk = batch - s * n_blocks, k = s & ((1u << group_log2) - 1u), ppw_log2 = 6u - group_log2;
-        return ((s - k) + (lane_id() >> ppw_log2)) * n_pix + (blk << 6) + (k << ppw_log2) + (lane_id() & ((1u << ppw_log2) - 1u));
-    };
+    auto at_of = [&](uint32_t batch) -> SlotAt { return px.group_log2 ? slot_at(px, batch, lane_id()) : slot_at(px, batch * B + lane_id()); };
     BatchCursor cursor(&cc->work_trace[0][0]);
     uint32_t bi = cursor.grab(), bi_next = cursor.grab();
     uint32_t pid_next = 0;
-    if (bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, px, slot_of(bi));
+    if (bi < n_batches && bi * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&K->gen, at_of(bi));
     for (; bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
-        const uint32_t i = slot_of(bi);
+        const uint32_t i = bi * B + lane_id();
         const uint32_t pid = pid_next;
         const bool active = i < n && lane_id() < B;
         // ---- closest hit; the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
         Ray ro{0, 0, 0, 0, 0, 0};
         {
             const FT_CONST PrimaryArgs* Kb = fresh(K);              // camera, pixel list: loaded here, dead before the trace
-            if (bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, px, slot_of(bi_next));
+            if (bi_next < n_batches && bi_next * B + lane_id() < n && lane_id() < B) pid_next = primary_pixel(&Kb->gen, at_of(bi_next));
             if (active) {
-                const Ray r = primary_ray_from(&Kb->gen, px, i, pid);
+                const Ray r = primary_ray_from(&Kb->gen, at_of(bi).s, pid);
                 ro = {r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
             }
         }
@@ -1427,7 +1433,7 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
             if (hit) {
                 sf = surface_at<FANCY>(S, ro, q.best_t, q.id0, q.id1);
                 lit = reinterpret_cast<cup>(S.materials + 8ull * sf.material + 6)[0] != 0;
-                if (SOFT) sample = (unsigned long long)pid * (unsigned long long)fresh(K)->gen.spp + div_by(i, px.inv);
+                if (SOFT) sample = (unsigned long long)pid * (unsigned long long)fresh(K)->gen.spp + at_of(bi).s;
             }
             unsigned long long vis_lo, vis_hi;
             light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, 0, coherent, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
@@ -1435,7 +1441,7 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
             if (FANCY) { if (hit && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
             // the view ray is generated again here rather than kept in registers across the shadow traces (same arithmetic, same value)
             const FT_CONST PrimaryArgs* K2 = fresh(K);
-            const Ray rv = hit ? primary_ray_from(&K2->gen, px, i, pid) : Ray{0, 0, 0, 0, 0, 0};
+            const Ray rv = hit ? primary_ray_from(&K2->gen, at_of(bi).s, pid) : Ray{0, 0, 0, 0, 0, 0};
             shade_lights<FANCY, SOFT>(S, sf, mat, rv, hit, lit, vis_lo, vis_hi, cr, cg, cb);
             // reflectionShader (Shading.fs:89-98), see k_bounce: one ray of weight L * reflectance stands for the L identical sub-traces
             const bool spawn = lit && mat.reflectance > 0.0 && 0 < K2->max_depth;
@@ -1871,10 +1877,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs a) {
     uint32_t n_pix = a.n_pix_host;                                  // all pixels of the chunk, or its window of the frame's active list (k_classify)
     if (a.counts) { const uint32_t n_active = a.counts->n_pix; n_pix = n_active > a.first ? (n_active - a.first < a.n_pix_host ? n_active - a.first : a.n_pix_host) : 0u; }
     const double spp = (double)a.spp;
+    const uint32_t group_log2 = (n_pix & 63u) ? 0u : a.group_log2;    // as pix_count decides it
     for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += gridDim.x * kBlock) {
         double r = 0.0, g = 0.0, b = 0.0;
         for (int s = 0; s < a.spp; ++s) {
-            const size_t i = (size_t)s * n_pix + q;
+            const size_t i = slot_of(n_pix, n_pix >> 6, group_log2, (uint32_t)s, q);   // the sample's place in the colour planes (slot_at)
             r += a.acc[i]; g += a.acc[(size_t)a.acc_stride + i]; b += a.acc[2 * (size_t)a.acc_stride + i];
         }
         const uint32_t al = a.first + q;                            // position in the active list -> position in the original pixel list
