@@ -47,7 +47,7 @@ struct ft_context {
     double commit_ms[4] = {0, 0, 0, 0};   // last ft_scene_commit: flatten on the host, device BVH builds, uploads + the rest, BVH height (not a time)
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
-    int wave_samples_log2 = -1;     // bounce-0 wavefronts take 2^this samples of 64 / 2^this pixels when the sample count allows (option wave_samples); -1: by scene
+    int wave_samples_log2 = -1;     // bounce-0 wavefronts take 2^this samples of 64 / 2^this pixels when the sample count allows (option wave_samples); -1: the default, 16
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
     int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
@@ -265,8 +265,8 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "csg_mesh_capacity")) { if (value < 1 || value > 255) return FT_ERR_INVALID; c->graph.csg_mesh_capacity = (int32_t)value; c->committed = false; return FT_OK; }
     if (!std::strcmp(key, "coherent_waves")) { c->coherent_waves = value != 0; c->dev_scene.coherent_waves = value != 0 ? 1 : 0; for (ft_context* p : c->peers) { p->coherent_waves = value != 0; p->dev_scene.coherent_waves = c->dev_scene.coherent_waves; } return FT_OK; }
     if (!std::strcmp(key, "wave_samples")) {
-        int l = 0; while ((1ll << l) < value) ++l;                 // 0: chosen by scene (the default); 1, 2, 4 ... 64: that many samples per wavefront
-        if (value < 0 || value > 64 || (value > 0 && (1ll << l) != value)) return FT_ERR_INVALID;
+        int l = 0; while ((1ll << l) < value) ++l;                 // 0: the default (16); 1, 2, 4, 8, 16: that many samples per wavefront (k_resolve's LDS tile holds 16)
+        if (value < 0 || value > 16 || (value > 0 && (1ll << l) != value)) return FT_ERR_INVALID;
         if (value == 0) l = -1;
         c->wave_samples_log2 = l; for (ft_context* p : c->peers) p->wave_samples_log2 = l; return FT_OK;
     }

@@ -1831,9 +1831,8 @@ FT_DEV void write_pixel(double* out_rgb, uint8_t* out_rgba, size_t o, double r, 
 // The end of a frame: the last workgroup to get here copies what the host wants of the counters into the pinned report and clears
 // the counters for the next frame.  Every other workgroup has finished with them (the ticket is taken after a workgroup's last
 // access) and the kernels that wrote them ended before this one began.
-FT_DEV void hand_over_frame(FrameCounters* fc, FrameReport* report) {
+FT_DEV void hand_over_frame(FrameCounters* fc, FrameReport* report, unsigned long long* cells) {   // cells: 8 KB of LDS
     __shared__ uint32_t last;
-    __shared__ unsigned long long cells[kStatStripes * 16];
     const uint32_t t = threadIdx.x;
     __syncthreads();
     // no fence: what is handed over was written by earlier kernels, and this workgroup's own reads of the counters returned long ago
@@ -1871,23 +1870,75 @@ FT_DEV void hand_over_frame(FrameCounters* fc, FrameReport* report) {
     uint4* z = reinterpret_cast<uint4*>(fc);
     for (uint32_t w = threadIdx.x; w < sizeof(FrameCounters) / 16; w += kBlock) z[w] = uint4{0u, 0u, 0u, 0u};
 }
-__global__ __launch_bounds__(kBlock) void k_report(FrameCounters* fc, FrameReport* report) { hand_over_frame(fc, report); }
+__global__ __launch_bounds__(kBlock) void k_report(FrameCounters* fc, FrameReport* report) {
+    __shared__ unsigned long long cells[kStatStripes * 16];
+    hand_over_frame(fc, report, cells);
+}
+
+// k_resolve under grouped numbering (slot_at): the G samples of a pixel under consecutive offsets lie 64 / G doubles apart in ONE
+// 512-byte run shared with its 64 / G - 1 neighbours, and the 64 pixels of a block in G such runs.  A wave reads the G runs of the three
+// colour planes whole (3 G coalesced loads in flight per lane), passes them through LDS plane by plane, and every lane then sums its own
+// pixel's samples in sample order: each colour is fetched once, in full lines (reading them pixel by pixel touches four times as many
+// lines per instruction).  The tile is the wave's own: the LDS keeps one wave's accesses in order, so a compiler barrier is all that
+// stands between the stores and the loads of other lanes' words.
+template <int GL, class Emit>
+FT_DEV void resolve_grouped(const ResolveArgs& a, uint32_t n_pix, double* T, Emit&& emit) {
+    constexpr uint32_t G = 1u << GL, pw = 6u - GL, ppw = 1u << pw, row = 64u + ppw;   // rows padded so that the 64 / G-lane groups fall on different banks
+    const uint32_t nb = n_pix >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, waves_total = gridDim.x * (kBlock / 64);
+    const uint32_t mine = (lane >> pw) * row + (lane & (ppw - 1u));
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    for (uint32_t blk = blockIdx.x * (kBlock / 64) + wave; blk < nb; blk += waves_total) {
+        double sum[3] = {0.0, 0.0, 0.0};
+        for (uint32_t s0 = 0; s0 < (uint32_t)a.spp; s0 += G) {
+            double v[3][G];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (uint32_t k = 0; k < G; ++k) v[p][k] = a.acc[(size_t)p * a.acc_stride + ((((size_t)(s0 + k)) * nb + blk) << 6) + lane];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (uint32_t k = 0; k < G; ++k) T[k * row + lane] = v[p][k];
+                wave_sync();
+#pragma unroll
+                for (uint32_t ds = 0; ds < G; ++ds) sum[p] += T[mine + (ds << pw)];
+                wave_sync();
+            }
+        }
+        emit((blk << 6) + lane, sum[0], sum[1], sum[2]);
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs a) {
+    __shared__ double tile[(kBlock / 64) * 8 * 136];                // per wave 8 x 136 doubles >= G rows of 64 + 64 / G for G = 2 .. 16 (and 8 KB for the hand-over)
     uint32_t n_pix = a.n_pix_host;                                  // all pixels of the chunk, or its window of the frame's active list (k_classify)
     if (a.counts) { const uint32_t n_active = a.counts->n_pix; n_pix = n_active > a.first ? (n_active - a.first < a.n_pix_host ? n_active - a.first : a.n_pix_host) : 0u; }
     const double spp = (double)a.spp;
     const uint32_t group_log2 = (n_pix & 63u) ? 0u : a.group_log2;    // as pix_count decides it
-    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += gridDim.x * kBlock) {
-        double r = 0.0, g = 0.0, b = 0.0;
-        for (int s = 0; s < a.spp; ++s) {
-            const size_t i = slot_of(n_pix, n_pix >> 6, group_log2, (uint32_t)s, q);   // the sample's place in the colour planes (slot_at)
-            r += a.acc[i]; g += a.acc[(size_t)a.acc_stride + i]; b += a.acc[2 * (size_t)a.acc_stride + i];
-        }
+    auto emit = [&](uint32_t q, double r, double g, double b) {
         const uint32_t al = a.first + q;                            // position in the active list -> position in the original pixel list
         const uint32_t p = a.pos_block ? a.pos_block[al >> 6] * 64u + (al & 63u) : al;
         write_pixel(a.out_rgb, a.out_rgba, a.pixel_ids ? (size_t)a.pixel_ids[p] : (size_t)p, r / spp, g / spp, b / spp);
+    };
+    if (group_log2 == 0u) {
+        for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += gridDim.x * kBlock) {
+            double r = 0.0, g = 0.0, b = 0.0;
+            for (int s = 0; s < a.spp; ++s) {
+                const size_t i = (size_t)s * n_pix + q;
+                r += a.acc[i]; g += a.acc[(size_t)a.acc_stride + i]; b += a.acc[2 * (size_t)a.acc_stride + i];
+            }
+            emit(q, r, g, b);
+        }
+    } else {
+        double* T = tile + (threadIdx.x >> 6) * (8 * 136);
+        switch (group_log2) {
+            case 1: resolve_grouped<1>(a, n_pix, T, emit); break;
+            case 2: resolve_grouped<2>(a, n_pix, T, emit); break;
+            case 3: resolve_grouped<3>(a, n_pix, T, emit); break;
+            default: resolve_grouped<4>(a, n_pix, T, emit); break;
+        }
     }
+    __syncthreads();                                                // the tile serves the hand-over next
     if (a.block_pos) {                                              // one wave per finished block: Colour.Zero for its 64 pixels
         const uint32_t lane = threadIdx.x & 63u;
         for (uint32_t blk = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; blk < a.n_blocks_total; blk += gridDim.x * (kBlock / 64)) {
@@ -1896,7 +1947,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs a) {
             write_pixel(a.out_rgb, a.out_rgba, a.pixel_ids ? (size_t)a.pixel_ids[p] : (size_t)p, 0.0, 0.0, 0.0);
         }
     }
-    if (a.report) hand_over_frame(a.fc, a.report);
+    if (a.report) hand_over_frame(a.fc, a.report, reinterpret_cast<unsigned long long*>(tile));
 }
 
 __global__ __launch_bounds__(kBlock) void k_resolve_corner(const double* __restrict__ acc, uint32_t acc_stride, uint32_t w, uint32_t h,
