@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="same as --workload headline: the 1080p x 16 frame strong-scaled")
     ap.add_argument("--weak", action="store_true", help="same as --workload weak")
     ap.add_argument("--side-steps", type=int, default=5, help="frames timed for each workload other than the primary one (0 = skip them)")
+    ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed frames queued for this long before the W warm-up steps of every workload (clock ramp); 0 = none")
     ap.add_argument("--blocking", action="store_true", help="render the timed frames one synchronous ft_render at a time instead of queuing them")
     args = ap.parse_args()
 
@@ -147,6 +148,12 @@ def main():
             _, st = ctx.render(scene.camera, res_h, res_v, spp, jitter, tiles=bands, fetch=False)
             return st
 
+        if args.prewarm_ms > 0:                                    # clocks: a fresh box idles low and 20 frames are 7 ms - queue frames for a while first,
+            t_end = time.perf_counter() + args.prewarm_ms / 1e3    # untimed like the W warm-up steps that follow, so the K steps run at the clocks a stream of frames sees
+            while time.perf_counter() < t_end:
+                for _ in range(32):
+                    ctx.render_enqueue(scene.camera, res_h, res_v, spp, jitter, tiles=bands)
+                ctx.wait()
         for _ in range(warmup):
             step()
         barrier_sync()

@@ -2056,7 +2056,12 @@ void launch_bounce(const Launch& L, const DevScene& S, const Primary& gen, RayBu
 }
 void launch_resolve(const Launch& L, const ResolveArgs& a) {
     const uint32_t work = a.block_pos ? (a.n_blocks_total * 64u > a.n_pix_host ? a.n_blocks_total * 64u : a.n_pix_host) : a.n_pix_host;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, L.grid)), dim3(kBlock), 0, L.stream, a);
+    // one resident round of workgroups (the grouped path holds 3 x 16 colours per lane: fewer waves fit than L.grid assumes), so that
+    // the hand-over at the end waits for one generation of workgroups, not for several
+    static int resident = 0;
+    if (!resident) { int n = 0; resident = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_resolve, kBlock, 0) == hipSuccess && n > 0) ? n : 2; }
+    const int cus = L.grid / 8;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, cus * resident)), dim3(kBlock), 0, L.stream, a);
 }
 void launch_report(const Launch& L, FrameCounters* fc, FrameReport* report) { hipLaunchKernelGGL(k_report, dim3(1), dim3(kBlock), 0, L.stream, fc, report); }
 void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba) {
