@@ -142,12 +142,13 @@ void    ft_destroy(ft_context* ctx);
 const char* ft_last_error(const ft_context* ctx);
 /* Tunables: "chunk_samples" (samples in flight per launch; default 16 Mi, frames whose pixel blocks are classified use twice that), "csg_mesh_capacity" (hit-list entries a mesh may add under
  * CSG; default 32), "csg_auto_grow" (default 1: a blocking ft_render (and the ft_debug_* ray queries) whose hit lists overflow doubles that capacity, re-commits and renders the
- * frame again instead of returning FT_ERR_OVERFLOW; the error remains for lists that stop fitting in the LDS and for ft_render_enqueue), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around every
- * k_closest / k_shade launch, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
+ * frame again instead of returning FT_ERR_OVERFLOW; the error remains for lists that stop fitting in the LDS and for ft_render_enqueue), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around
+ * k_primary and the k_bounce levels, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
  * cannot reach any object are finished before any ray is generated; the bundle is bounded from the jitter pattern handed to ft_render, whatever its range), "level_hint" (default 1: a frame launches as many levels of the reflection tree as the
  * previous frame of the same scene, size and samples had rays in, plus one, whose rays are followed to the end inside the launch; 0: always max_depth levels), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits), "bvh_builder" (1 = default: the exact BVH of top-level-Leaf meshes is a linear BVH built on the
- * device at commit; 0: the host's recursive median split).  Scene-affecting options need a new ft_scene_commit. */
+ * device at commit; 0: the host's recursive median split), "wave_samples" (0 = default, 16: a bounce-0 wavefront takes up to that many jitter offsets of 64 / that many pixels of an
+ * 8x8 block when the sample count has the power of two in it - a narrower bundle; 1, 2, 4, 8, 16; no pixel depends on it).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
 
 /* ---- scene graph builder (Scene.fs:8-53) ------------------------------------------------- */
