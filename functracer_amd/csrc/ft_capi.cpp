@@ -32,6 +32,7 @@ enum { kStageOther = 0, kStageClosest = 1, kStageShade = 2, kStageResolve = 3, k
 // What a frame copies back when it retires: FrameCounters from `stats` to its end.
 static_assert(sizeof(ftk::FrameCounters) % 16 == 0 && offsetof(ftk::RenderCounters, ref_equiv) == 32, "the hand-over at the end of a frame copies words and clears 16 bytes at a time");
 
+constexpr int64_t kDeviceBvhMinTris = 4096;   // "bvh_builder" = 2: smaller meshes get the host's SAH tree (a few ms at most), larger ones the device's linear BVH
 struct ft_context {
     std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
     bool host_only = false;
@@ -43,7 +44,9 @@ struct ft_context {
     fth::SceneGraph graph;
     fth::FlatScene flat;
     bool committed = false;
-    int bvh_builder = 1;            // who builds the exact BVH of top-level-Leaf meshes: 1 = the device (ft_bvh.hip), 0 = the host's median split
+    int bvh_builder = 2;            // who builds the exact BVH of top-level-Leaf meshes: 1 = the device (ft_bvh.hip: linear BVH), 0 = the host (surface-area
+                                    // sweep), 2 = by size: the host's tree traces 7-11 % faster and takes 1.2 ms for 980 triangles but 177 ms for 69.6 K,
+                                    // the device's 0.4 and 8 ms, so meshes of kDeviceBvhMinTris triangles and more are built on the device
     double commit_ms[4] = {0, 0, 0, 0};   // last ft_scene_commit: flatten on the host, device BVH builds, uploads + the rest, BVH height (not a time)
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
@@ -274,7 +277,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
     if (!std::strcmp(key, "level_hint")) { c->level_hint = value != 0; for (ft_context* p : c->peers) p->level_hint = value != 0; return FT_OK; }
-    if (!std::strcmp(key, "bvh_builder")) { if (value < 0 || value > 1) return FT_ERR_INVALID; c->bvh_builder = (int)value; c->committed = false; return FT_OK; }
+    if (!std::strcmp(key, "bvh_builder")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->bvh_builder = (int)value; c->committed = false; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
     return FT_ERR_INVALID;
@@ -383,11 +386,12 @@ int32_t ft_scene_commit(ft_context* c) {
     using clock = std::chrono::steady_clock;
     auto ms_since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
     for (double& v : c->commit_ms) v = 0.0;
-    // A device context builds the exact BVH of top-level-Leaf meshes on the device ("bvh_builder" = 1, the default): the flattener
+    // A device context builds the exact BVH of top-level-Leaf meshes on the device ("bvh_builder" = 1; 2, the default: from 4096 triangles on): the flattener
     // reserves the ranges, upload_scene fills them.  A build the device refuses (a tree too deep for the traversal stacks) falls
-    // back to the host's median split, once, for the whole scene.
+    // back to the host's builder, once, for the whole scene.
     for (int attempt = 0; attempt < 2; ++attempt) {
-        c->graph.device_bvh = !c->host_only && c->bvh_builder == 1 && attempt == 0;
+        c->graph.device_bvh = !c->host_only && c->bvh_builder >= 1 && attempt == 0;
+        c->graph.device_bvh_min_tris = c->bvh_builder == 2 ? kDeviceBvhMinTris : 0;
         auto t0 = clock::now();
         int32_t rc = c->graph.flatten(c->flat, c->err);
         c->commit_ms[0] += ms_since(t0);

@@ -175,7 +175,7 @@ struct Flattener {
     uint32_t mesh_for(int32_t node_id, const double* tris, int64_t n, int32_t depth) {
         if (node_id >= 0) { auto it = mesh_of_node.find(node_id); if (it != mesh_of_node.end()) return it->second; }
         ftd::Mesh m{};
-        int32_t rc = build_bsp(tris, n, depth, out, m, err, g.device_bvh);
+        int32_t rc = build_bsp(tris, n, depth, out, m, err, g.device_bvh && n >= g.device_bvh_min_tris);
         if (rc != FT_OK) { status = rc; return 0; }
         out.meshes.push_back(m);
         {
@@ -539,13 +539,43 @@ struct BspBuilder {
                 if (c > cb.hi[a]) cb.hi[a] = c;
             }
         }
+        // Split by the surface-area heuristic, swept exactly: along each axis the triangles are ordered by centroid and every cut is
+        // priced as area(left) x count(left) + area(right) x count(right); ties and degenerate sweeps fall back to the median of the
+        // widest axis.  (The tree only decides which boxes a ray looks into: no pixel depends on it.)
         int axis = 0;
         for (int a = 1; a < 3; ++a) if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
-        const size_t mid = (lo + hi) / 2;
-        std::nth_element(idx.begin() + (long)lo, idx.begin() + (long)mid, idx.begin() + (long)hi, [&](uint32_t x, uint32_t y) {
-            const double cx = boxes[x].lo[axis] + boxes[x].hi[axis], cy = boxes[y].lo[axis] + boxes[y].hi[axis];
-            return cx < cy || (cx == cy && x < y);
-        });
+        size_t mid = (lo + hi) / 2;
+        auto by_centroid = [&](int ax) {
+            return [&boxes, ax](uint32_t x, uint32_t y) {
+                const double cx = boxes[x].lo[ax] + boxes[x].hi[ax], cy = boxes[y].lo[ax] + boxes[y].hi[ax];
+                return cx < cy || (cx == cy && x < y);
+            };
+        };
+        if (hi - lo <= 65536) {                                    // above that a level's three sorts cost more than its cut returns: medians
+            const size_t n = hi - lo;
+            auto area = [](const Box& q) { const double dx = q.hi[0] - q.lo[0], dy = q.hi[1] - q.lo[1], dz = q.hi[2] - q.lo[2]; return dx * dy + dy * dz + dz * dx; };
+            double best = std::numeric_limits<double>::infinity();
+            int best_axis = -1; size_t best_cut = 0;
+            std::vector<double> right_area(n);
+            std::vector<uint32_t> order(idx.begin() + (long)lo, idx.begin() + (long)hi);
+            for (int ax = 0; ax < 3; ++ax) {
+                std::sort(order.begin(), order.end(), by_centroid(ax));
+                Box acc{{inf, inf, inf}, {-inf, -inf, -inf}};
+                for (size_t k = n; k-- > 1;) {
+                    for (int a = 0; a < 3; ++a) { acc.lo[a] = std::min(acc.lo[a], boxes[order[k]].lo[a]); acc.hi[a] = std::max(acc.hi[a], boxes[order[k]].hi[a]); }
+                    right_area[k] = area(acc);
+                }
+                acc = Box{{inf, inf, inf}, {-inf, -inf, -inf}};
+                for (size_t k = 1; k < n; ++k) {                    // cut before element k: [0, k) | [k, n)
+                    for (int a = 0; a < 3; ++a) { acc.lo[a] = std::min(acc.lo[a], boxes[order[k - 1]].lo[a]); acc.hi[a] = std::max(acc.hi[a], boxes[order[k - 1]].hi[a]); }
+                    const double cost = area(acc) * (double)k + right_area[k] * (double)(n - k);
+                    if (cost < best) { best = cost; best_axis = ax; best_cut = k; }
+                }
+            }
+            if (best_axis >= 0 && std::isfinite(best)) { axis = best_axis; mid = lo + best_cut; }
+            if (level > 24) mid = (lo + hi) / 2;                    // a lopsided sweep must not outgrow the walkers' stacks (40 levels): medians from here on
+        }
+        std::sort(idx.begin() + (long)lo, idx.begin() + (long)hi, by_centroid(axis));
         const int32_t node = (int32_t)out.nodes.size();
         out.nodes.push_back(ftd::BspNode{});
         const int32_t l = bvh_build(ts, boxes, idx, lo, mid, first_global, pad, level + 1);

@@ -73,8 +73,9 @@ struct SceneGraph {
     // hit arithmetic differs in the last bits, so pixels may differ at the 1e-12 level (and on silhouette ties).
     bool mesh_unclipped_bvh = false;
     // Who builds the exact BVH of top-level-Leaf meshes: true = the device (linear BVH, ft_bvh.hip; device contexts' default),
-    // false = the host's recursive median split (host-only contexts, and the fallback when a device build is refused).
+    // false = the host's recursive surface-area sweep (host-only contexts, and the fallback when a device build is refused).
     bool device_bvh = false;
+    int64_t device_bvh_min_tris = 0;   // with device_bvh: meshes with fewer triangles than this get the host's SAH tree (better tree, slower build)
 
     bool valid(int32_t id) const { return id >= 0 && id < (int32_t)nodes.size(); }
     // Returns FT_OK or a negative ft_status with err set.

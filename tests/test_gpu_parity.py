@@ -556,8 +556,8 @@ def test_jitter_offsets_outside_the_unit_disc(hip):
 
 
 def test_device_built_bvh_equals_host_built_bvh(hip):
-    """The exact BVH of a `bspMesh 0` is built on the device by default (linear BVH, ft_bvh.hip) and by the host's median split
-    with "bvh_builder" = 0.  Both stand in for the reference's linear scan (BspMesh.fs:95-97): closest hits (ties included: many
+    """The exact BVH of a `bspMesh 0` is built on the device (linear BVH, ft_bvh.hip; "bvh_builder" = 1) or by the host's surface-area
+    sweep (0); the default (2) takes the host's tree below 4096 triangles and the device's from there on.  Both stand in for the reference's linear scan (BspMesh.fs:95-97): closest hits (ties included: many
     coincident triangles, whose hits must go to the lowest list index), shadow queries and frames agree bit for bit with each
     other, and with the oracle's brute force within the contract."""
     rng = np.random.default_rng(11)
@@ -570,7 +570,7 @@ def test_device_built_bvh_equals_host_built_bvh(hip):
     jit = ft.jitter_pattern(2)
     results = {}
     try:
-        for builder in (0, 1):
+        for builder in (0, 1, 2):
             hip.set_option("bvh_builder", builder)
             hip.clear()
             hip.set_objects(hip.group([hip.material(hip.bsp_mesh(0, tris.reshape(-1, 9)), colour=(0.9, 0.5, 0.2), shineyness=4.0)]))
@@ -578,14 +578,23 @@ def test_device_built_bvh_equals_host_built_bvh(hip):
             hip.add_positional((2, 3, -2), (1, 0.1, 0.01), (0.5, 0.5, 1.0))
             hip.commit()
             ct = hip.commit_times()
-            assert (ct["device_bvh_height"] > 0) == (builder == 1) and (ct["device_bvh_ms"] > 0) == (builder == 1)
+            assert (ct["device_bvh_height"] > 0) == (builder == 1) and (ct["device_bvh_ms"] > 0) == (builder == 1)   # 3000 triangles: the default asks the host
             results[builder] = (hip.closest(o, d), hip.blocked(o, d, md), hip.render(cam, 320, 240, 2, jit)[0])
+        big = np.concatenate([tris, tris[:1500] + 0.01])            # 4500 triangles: past the default's threshold
+        hip.clear()
+        hip.set_objects(hip.group([hip.bsp_mesh(0, big.reshape(-1, 9))]))
+        hip.add_directional((1, -2, 1), (1, 1, 1))
+        hip.commit()
+        assert hip.commit_times()["device_bvh_height"] > 0
     finally:
-        hip.set_option("bvh_builder", 1)
+        hip.set_option("bvh_builder", 2)
     (c0, b0, f0), (c1, b1, f1) = results[0], results[1]
     for x, y in zip(c0, c1):
         assert np.array_equal(x, y)
     assert np.array_equal(b0, b1) and np.array_equal(f0, f1)
+    for x, y in zip(c0, results[2][0]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(b0, results[2][1]) and np.array_equal(f0, results[2][2])
     orc = O.Oracle()
     orc.clear()
     orc.set_objects(orc.group([orc.material(orc.bsp_mesh(0, tris.reshape(-1, 9)), colour=(0.9, 0.5, 0.2), shineyness=4.0)]))
@@ -606,12 +615,16 @@ def test_device_bvh_refuses_a_non_finite_mesh_and_the_host_takes_over(hip):
     tris[7, 1, 2] = np.nan
     cam = ft.make_camera((0, 0, -4), (0, 0, 0), (0, 1, 0), H.deg(40.0), 1.0)
     frames = []
-    for b in (hip, O.Oracle()):
-        b.clear()
-        b.set_objects(b.group([b.bsp_mesh(0, tris.reshape(-1, 9))]))
-        b.add_directional((0, -1, 1), (1, 1, 1))
-        b.commit()
-        frames.append(b.render(cam, 96, 96, 1, np.zeros((1, 2)))[0])
+    hip.set_option("bvh_builder", 1)                                # the device builder is asked, whatever the size
+    try:
+        for b in (hip, O.Oracle()):
+            b.clear()
+            b.set_objects(b.group([b.bsp_mesh(0, tris.reshape(-1, 9))]))
+            b.add_directional((0, -1, 1), (1, 1, 1))
+            b.commit()
+            frames.append(b.render(cam, 96, 96, 1, np.zeros((1, 2)))[0])
+    finally:
+        hip.set_option("bvh_builder", 2)
     assert hip.commit_times()["device_bvh_height"] == 0            # the scene in HBM is the host-built one
     assert H.assert_frames_match(frames[0], frames[1], what="NaN vertex") < 1e-6
 

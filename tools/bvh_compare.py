@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host median-split BVH against the device-built linear BVH (ft_bvh.hip): commit time, tree height, frame time at 1920x1080 and
+"""Host surface-area-sweep BVH against the device-built linear BVH (ft_bvh.hip): commit time, tree height, frame time at 1920x1080 and
 bit-identity of the frames (both trees are exact stand-ins for the reference's linear scan).  GPU box: python tools/bvh_compare.py"""
 import json
 import os
@@ -38,7 +38,7 @@ for name, spp, unclipped in CASES:
         ctx.fetch_frame(f)
         frames[builder] = f
         c = min(commits, key=lambda q: q["lower_and_commit_ms"])
-        row = {"builder": "device LBVH" if builder else "host median split", "triangles": ctx.scene_info()["triangles"],
+        row = {"builder": "device LBVH" if builder else "host surface-area sweep", "triangles": ctx.scene_info()["triangles"],
                "commit": {k: round(v, 3) if isinstance(v, float) else v for k, v in c.items()}, "frame_kernel_ms": round(best["kernel_ms"], 3),
                "k_primary_ms": round(kt["primary"]["ms"], 3), "rays_traced": best["rays_traced"]}
         out[f"{name} builder={builder}"] = row
