@@ -14,7 +14,8 @@ Every line carries all of them (`workloads`), each timed the same way, so any tw
 
 A step = one full frame of the timed workload: every rank renders its bands through the C ABI with the frame left in HBM
 (out_rgb = NULL); scene, jitter pattern and pixel lists are HBM-resident before the timed region.  The K steps are bracketed
-by barrier + device synchronise and the slowest rank's wall time counts.
+by barrier + device synchronise and the slowest rank's wall time counts.  Before the W warm-up steps untimed frames are queued for
+--prewarm-ms (200): a fresh box idles at low clocks, and K = 20 steps are 6 ms.
 
 `value` = rays the devices TRACED (ft_stats.rays_traced: generated primaries + shadow + reflection rays; primaries of 64-pixel
 blocks that k_classify proves empty are never generated and are NOT counted) / that time.  `value_reference_equivalent` is the
