@@ -1196,11 +1196,6 @@ FT_DEV SlotAt slot_at(const Pix& px, uint32_t slot) {
     if (px.group_log2 == 0u) { const uint32_t s = div_by(slot, px.inv); return {s, slot - s * px.n}; }
     return slot_at(px, slot >> 6, slot & 63u);
 }
-FT_DEV uint32_t slot_of(uint32_t n_pix, uint32_t n_blocks, uint32_t group_log2, uint32_t s, uint32_t pl) {
-    if (group_log2 == 0u) return s * n_pix + pl;
-    const uint32_t g1 = (1u << group_log2) - 1u, pw = 6u - group_log2, w = pl & 63u;
-    return ((((s & ~g1) + (w >> pw)) * n_blocks + (pl >> 6)) << 6) + (((s & g1) << pw) | (w & ((1u << pw) - 1u)));
-}
 
 // Pixel id behind entry `at` of the chunk's list.  In a classified frame the list is the frame's ACTIVE list, kept as a map from
 // its 64-pixel blocks to the blocks of the original pixel list (k_classify): the ids themselves are never copied.
