@@ -1,16 +1,16 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over the HOST side of the product (scene graph, flattening, BSP / BVH builders, C-ABI argument handling,
-# scene / PLY / image parsers): builds sanitized copies of both libraries under build/asan (g++; the device object is linked as it
-# is) and runs the CPU test suite and a flatten of every scene in scenes/ against them.  CPU only - GPU sanitizers are not available.
+# scene / PLY / image parsers): builds sanitized copies of both libraries under build/asan (g++; the device objects are linked as they
+# are) and runs the CPU test suite and a flatten of every scene in scenes/ against them.  CPU only - GPU sanitizers are not available.
 #   tools/sanitize_host.sh        -> prints the sanitizer findings (none expected) and the pytest summary
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd "$ROOT"
-make -s -C functracer_amd/csrc ft_kernels.o
+make -s -C functracer_amd/csrc ft_kernels.o ft_bvh.o
 mkdir -p build/asan
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1 -std=c++17 -fPIC -ffp-contract=off"
 g++ $SAN -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c functracer_amd/csrc/ft_capi.cpp -o build/asan/ft_capi.o
 g++ $SAN -c functracer_amd/csrc/ft_scene.cpp -o build/asan/ft_scene.o
-g++ $SAN -shared -o build/asan/libfunctracer_hip.so build/asan/ft_capi.o build/asan/ft_scene.o functracer_amd/csrc/ft_kernels.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+g++ $SAN -shared -o build/asan/libfunctracer_hip.so build/asan/ft_capi.o build/asan/ft_scene.o functracer_amd/csrc/ft_kernels.o functracer_amd/csrc/ft_bvh.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 (cd functracer_amd/host && g++ $SAN -shared -o "$ROOT/build/asan/libfunctracer_host.so" SceneParser.cpp ImageLoader.cpp host_api.cpp -lz)
 export FT_HIP_LIB=$ROOT/build/asan/libfunctracer_hip.so FT_HOST_LIB=$ROOT/build/asan/libfunctracer_host.so
 export LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libubsan.so)"
