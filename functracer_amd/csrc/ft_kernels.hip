@@ -650,16 +650,19 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #define FT_PUSH(c) asm("s_mov_b32 m0, %1\n\tv_writelane_b32 %0, %2, m0\n\ts_cmp_lg_u64 %3, 0\n\ts_addc_u32 %1, %1, 0" : "+v"(stack_lanes), "+s"(sp) : "s"(ch[c]), "s"(m[c]) : "m0", "scc")
+            // the nearest child is not pushed and popped again: when it is entered the walk goes straight on with it
+#define FT_NEXT(c) if (m[c]) { cur = ch[c]; continue; }
             switch (order) {                                        // bit 2: left half first; bit 1: slot 0 before 1; bit 0: slot 2 before 3
-                case 7: FT_PUSH(3); FT_PUSH(2); FT_PUSH(1); FT_PUSH(0); break;     // near to far 0 1 2 3
-                case 6: FT_PUSH(2); FT_PUSH(3); FT_PUSH(1); FT_PUSH(0); break;     // 0 1 3 2
-                case 5: FT_PUSH(3); FT_PUSH(2); FT_PUSH(0); FT_PUSH(1); break;     // 1 0 2 3
-                case 4: FT_PUSH(2); FT_PUSH(3); FT_PUSH(0); FT_PUSH(1); break;     // 1 0 3 2
-                case 3: FT_PUSH(1); FT_PUSH(0); FT_PUSH(3); FT_PUSH(2); break;     // 2 3 0 1
-                case 2: FT_PUSH(1); FT_PUSH(0); FT_PUSH(2); FT_PUSH(3); break;     // 3 2 0 1
-                case 1: FT_PUSH(0); FT_PUSH(1); FT_PUSH(3); FT_PUSH(2); break;     // 2 3 1 0
-                default: FT_PUSH(0); FT_PUSH(1); FT_PUSH(2); FT_PUSH(3); break;    // 3 2 1 0
+                case 7: FT_PUSH(3); FT_PUSH(2); FT_PUSH(1); FT_NEXT(0); break;     // near to far 0 1 2 3
+                case 6: FT_PUSH(2); FT_PUSH(3); FT_PUSH(1); FT_NEXT(0); break;     // 0 1 3 2
+                case 5: FT_PUSH(3); FT_PUSH(2); FT_PUSH(0); FT_NEXT(1); break;     // 1 0 2 3
+                case 4: FT_PUSH(2); FT_PUSH(3); FT_PUSH(0); FT_NEXT(1); break;     // 1 0 3 2
+                case 3: FT_PUSH(1); FT_PUSH(0); FT_PUSH(3); FT_NEXT(2); break;     // 2 3 0 1
+                case 2: FT_PUSH(1); FT_PUSH(0); FT_PUSH(2); FT_NEXT(3); break;     // 3 2 0 1
+                case 1: FT_PUSH(0); FT_PUSH(1); FT_PUSH(3); FT_NEXT(2); break;     // 2 3 1 0
+                default: FT_PUSH(0); FT_PUSH(1); FT_PUSH(2); FT_NEXT(3); break;    // 3 2 1 0
             }
+#undef FT_NEXT
 #undef FT_PUSH
 #pragma clang diagnostic pop
         } else {
