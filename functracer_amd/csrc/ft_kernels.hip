@@ -638,6 +638,12 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                 // an absent child's box is tested like any other and dropped here, so that no branch stands between the node's loads
                 m[c] = __builtin_amdgcn_ballot_w64(tmax >= fmax(tmin, 0.0)) & __builtin_amdgcn_ballot_w64(tmin <= reach) & (ch[c] == INT32_MIN ? 0ull : ~0ull);
             }
+            // At most one child entered (the usual case near the leaves): no order to work out, nothing to push.
+            {
+                const uint32_t n_in = (m[0] != 0ull ? 1u : 0u) + (m[1] != 0ull ? 1u : 0u) + (m[2] != 0ull ? 1u : 0u) + (m[3] != 0ull ? 1u : 0u);
+                if (n_in == 1u) { cur = m[0] ? ch[0] : m[1] ? ch[1] : m[2] ? ch[2] : ch[3]; continue; }
+                if (n_in == 0u) { if (sp == 0) break; --sp; cur = __builtin_amdgcn_readlane(stack_lanes, sp); continue; }
+            }
             // Visiting order, nearest first by the majority directions: halves by the node's axis, slots within a half by the child's.
             // The entered children go on the stack far to near and the common pop below takes the nearest; one of eight fixed
             // sequences is picked by three bits, so every push names its child statically (selecting m[c] / ch[c] by a computed c
