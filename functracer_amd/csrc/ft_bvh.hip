@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_bvh_emit(EmitArgs a) {
     int32_t child[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
     uint32_t axes = a.split_bit[i];
     const int32_t halves[2] = {a.left[i], a.right[i]};
-    for (int k = 0; k < 24; ++k) w[k] = 0.0;
+    for (int k = 0; k < 24; ++k) w[k] = __builtin_nan("");          // an empty slot's box fails every slab test by itself (ft_flat.h)
     for (int h = 0; h < 2; ++h) {
         const int32_t c = halves[h];
         if (scene_ref(a, c) < 0) { child[2 * h] = scene_ref(a, c); padded_box(a, c, pad, w + 6 * (2 * h)); continue; }

@@ -85,7 +85,7 @@ struct Mesh {
 // 4-wide BVH node for packet traversal (28 doubles): the boxes of up to four children live in the PARENT, so one scalar-load
 // round trip decides four subtrees (the two children of each child of a binary BVH node, collapsed):
 //   [6*c .. 6*c+5] = lo xyz, hi xyz of child c (c = 0,1: the left half; 2,3: the right half)
-//   [24], [25]     = int32 child[4]: >= 0 wide node, < 0 ~leaf index, INT32_MIN empty slot
+//   [24], [25]     = int32 child[4]: >= 0 wide node, < 0 ~leaf index, INT32_MIN empty slot (whose box is all NaN: no ray passes it)
 //   [26]           = uint32 axes: split axis of the binary node | of its left child << 8 | of its right child << 16
 constexpr int kWideNodeDoubles = 28;
 struct BspNode {           // 64 bytes; BspMesh.fs:12-19 (also used for BVH nodes)

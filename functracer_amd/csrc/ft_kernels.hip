@@ -635,8 +635,9 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
                 tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
                 // dead lanes carry reach = -inf, so the two comparisons are the whole test (no short-circuit: no exec-mask games)
                 // (one ballot per comparison: the compiler turns a ballot of anything but a bare comparison into a select and a second compare);
-                // an absent child's box is tested like any other and dropped here, so that no branch stands between the node's loads
-                m[c] = __builtin_amdgcn_ballot_w64(tmax >= fmax(tmin, 0.0)) & __builtin_amdgcn_ballot_w64(tmin <= reach) & (ch[c] == INT32_MIN ? 0ull : ~0ull);
+                // an absent child's box is tested like any other - the builders fill it with NaN, which no comparison passes - so that no
+                // branch stands between the node's loads
+                m[c] = __builtin_amdgcn_ballot_w64(tmax >= fmax(tmin, 0.0)) & __builtin_amdgcn_ballot_w64(tmin <= reach);
             }
             // At most one child entered (the usual case near the leaves): no order to work out, nothing to push.
             {

@@ -607,7 +607,8 @@ struct BspBuilder {
             for (int k = 0; k < 2; ++k) { box[2 * h + k] = box_of(gk[k]); child[2 * h + k] = gk[k] < 0 ? gk[k] : widen(gk[k]); }
         }
         double* w = &out.wide[at];
-        for (int c = 0; c < 4; ++c) for (int a = 0; a < 3; ++a) { w[6 * c + a] = box[c].lo[a]; w[6 * c + 3 + a] = box[c].hi[a]; }
+        const double absent = std::numeric_limits<double>::quiet_NaN();   // an empty slot's box fails every slab test by itself (ft_flat.h)
+        for (int c = 0; c < 4; ++c) for (int a = 0; a < 3; ++a) { w[6 * c + a] = child[c] == INT32_MIN ? absent : box[c].lo[a]; w[6 * c + 3 + a] = child[c] == INT32_MIN ? absent : box[c].hi[a]; }
         std::memcpy(w + 24, child, sizeof child);
         std::memcpy(w + 26, &axes, sizeof axes);
         return (int32_t)(at / ftd::kWideNodeDoubles);
