@@ -641,7 +641,9 @@ FT_DEV void mesh_bvh_packet(const Scene& S, int32_t wide_root, const Ray& r, Que
             }
             // At most one child entered (the usual case near the leaves): no order to work out, nothing to push.
             {
-                const uint32_t n_in = (m[0] != 0ull ? 1u : 0u) + (m[1] != 0ull ? 1u : 0u) + (m[2] != 0ull ? 1u : 0u) + (m[3] != 0ull ? 1u : 0u);
+                uint32_t n_in = 0u;                                  // counted on the scalar unit (the portable sum goes through two vector selects)
+                asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, 0\n\ts_cmp_lg_u64 %2, 0\n\ts_addc_u32 %0, %0, 0\n\ts_cmp_lg_u64 %3, 0\n\ts_addc_u32 %0, %0, 0\n\ts_cmp_lg_u64 %4, 0\n\ts_addc_u32 %0, %0, 0"
+                    : "+s"(n_in) : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]) : "scc");
                 if (n_in == 1u) { cur = m[0] ? ch[0] : m[1] ? ch[1] : m[2] ? ch[2] : ch[3]; continue; }
                 if (n_in == 0u) { if (sp == 0) break; --sp; cur = __builtin_amdgcn_readlane(stack_lanes, sp); continue; }
             }
