@@ -1592,6 +1592,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
                 break;
             }
             if (cnt == 0u) break;
+            if (lane_id() == 0) atomicAdd(&K2->fc->cc.n_rays[depth + 1], cnt);   // counted all the same: the host sizes the next frame's launches from these
             if (spawn) {                                            // followed in registers: same ray, same weight as the queued one would carry
                 r = {sf.p.x, sf.p.y, sf.p.z, r.dx - k2 * sf.n.x, r.dy - k2 * sf.n.y, r.dz - k2 * sf.n.z};
                 w = w * (mat.reflectance * (double)n_lights);

@@ -145,7 +145,8 @@ const char* ft_last_error(const ft_context* ctx);
  * frame again instead of returning FT_ERR_OVERFLOW; the error remains for lists that stop fitting in the LDS and for ft_render_enqueue), "timing" (HIP events recorded inside ft_render: 0 around the frame only, 1 = default: also around
  * k_primary and the k_bounce levels, 2 around every stage; each bracketed boundary costs about 6 us of stream time), "classify_pixels" (default 1: 64-pixel blocks whose ray bundle
  * cannot reach any object are finished before any ray is generated; the bundle is bounded from the jitter pattern handed to ft_render, whatever its range), "level_hint" (default 1: a frame launches as many levels of the reflection tree as the
- * previous frame of the same scene, size and samples had rays in, plus one, whose rays are followed to the end inside the launch; 0: always max_depth levels), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
+ * previous frame of the same scene, size and samples had rays in, plus one, whose rays are followed to the end inside the launch; 0: always max_depth levels), "follow_below" (levels in which that
+ * previous frame had no more rays than this are not worth a launch and are followed as well; -1 = default: two rays per SIMD of the device; 0: every level that had a ray), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits), "bvh_builder" (who builds the exact BVH of top-level-Leaf meshes at commit - 1: the device, a linear BVH; 0: the host, a
  * surface-area sweep (a better tree, a much slower build); 2 = default: the host below 4096 triangles, the device from there on), "wave_samples" (0 = default, 16: a bounce-0 wavefront takes up to that many jitter offsets of 64 / that many pixels of an
  * 8x8 block when the sample count has the power of two in it - a narrower bundle; 1, 2, 4, 8, 16; no pixel depends on it).  Scene-affecting options need a new ft_scene_commit. */
