@@ -699,8 +699,14 @@ def test_levels_launched_change_no_pixel_and_no_count(hip, name):
             b, sb = hip.render(p.camera, 160, 90, 2, jit, max_depth=depth)
             hip.set_option("level_hint", 1)
             assert np.array_equal(a, b) and sa["rays_reflect"] == sb["rays_reflect"]
+        for few in (0, 1000, 10 ** 9):                                                            # levels with few rays get no launch: every threshold, the same frame
+            hip.set_option("follow_below", few)
+            hip.render(p.camera, 160, 90, 2, jit)                                                  # sets the hint under this threshold
+            frames.append(hip.render(p.camera, 160, 90, 2, jit)); stats.append(frames[-1][1])
+        assert stats[-1]["n_launches"] < stats[0]["n_launches"]                                    # everything after level 1 followed
     finally:
         hip.set_option("level_hint", 1)
+        hip.set_option("follow_below", -1)
     assert stats[0]["rays_reflect"] > 0
     for (img, _), st in zip(frames[1:], stats[1:]):
         assert np.array_equal(img, frames[0][0])
