@@ -712,8 +712,13 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         bool tiled = true;
         for (const ft_rect& r : rects) {
             if (r.w % 8 == 0 && r.h % 8 == 0) {
+                // inside a block the pixels run in Z order (first its top-left corner, last its bottom-right one, as k_classify expects):
+                // the 4 or 16 consecutive pixels a wavefront takes under grouped numbering are a 2x2 or 4x4 square, not a strip
                 for (int ty = 0; ty < r.h; ty += 8) for (int tx = 0; tx < r.w; tx += 8)
-                    for (int iy = 0; iy < 8; ++iy) for (int ix = 0; ix < 8; ++ix) px.push_back((uint32_t)((r.y0 + ty + iy) * res_h + r.x0 + tx + ix));
+                    for (int k = 0; k < 64; ++k) {
+                        const int ix = (k & 1) | ((k >> 1) & 2) | ((k >> 2) & 4), iy = ((k >> 1) & 1) | ((k >> 2) & 2) | ((k >> 3) & 4);
+                        px.push_back((uint32_t)((r.y0 + ty + iy) * res_h + r.x0 + tx + ix));
+                    }
             } else {
                 tiled = false;
                 for (int y = r.y0; y < r.y0 + r.h; ++y) for (int x = r.x0; x < r.x0 + r.w; ++x) px.push_back((uint32_t)(y * res_h + x));
