@@ -149,12 +149,14 @@ def main():
             _, st = ctx.render(scene.camera, res_h, res_v, spp, jitter, tiles=bands, fetch=False)
             return st
 
+        prewarm_frames = 0
         if args.prewarm_ms > 0:                                    # clocks: a fresh box idles low and 20 frames are 7 ms - queue frames for a while first,
             t_end = time.perf_counter() + args.prewarm_ms / 1e3    # untimed like the W warm-up steps that follow, so the K steps run at the clocks a stream of frames sees
             while time.perf_counter() < t_end:
                 for _ in range(32):
                     ctx.render_enqueue(scene.camera, res_h, res_v, spp, jitter, tiles=bands)
                 ctx.wait()
+                prewarm_frames += 32
         for _ in range(warmup):
             step()
         barrier_sync()
@@ -179,7 +181,7 @@ def main():
         kernel_ms = sum(k_times.values())
         (wall_max, kernel_ms_max), (traced, ref_equiv, culled, listed) = reduce_max_sum(
             [wall, kernel_ms], [float(st["rays_traced"]), float(st["rays_reference_equivalent"]), float(st["rays_primary_culled"]), float(st["rays_primary"])])
-        return {"name": name, "res": (res_h, res_v), "spp": spp, "scaling": scaling, "steps": steps, "warmup": warmup, "bands": bands, "jitter": jitter,
+        return {"name": name, "res": (res_h, res_v), "spp": spp, "scaling": scaling, "steps": steps, "warmup": warmup, "bands": bands, "jitter": jitter, "prewarm_frames": prewarm_frames,
                 "wall_max": wall_max, "kernel_ms_max": kernel_ms_max, "rays_traced_frame": traced, "rays_ref_equiv_frame": ref_equiv,
                 "rays_culled_frame": culled, "rays_listed_frame": listed, "st": st, "k_times": k_times, "k_launch": k_launch}
 
@@ -281,6 +283,8 @@ def main():
             "n_gpus": world,
             "steps": steps,
             "warmup": P["warmup"],
+            "prewarm_ms": args.prewarm_ms,
+            "prewarm_frames": P["prewarm_frames"],
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": P["scaling"],
@@ -299,9 +303,12 @@ def main():
             "gather_ms": round(gather_ms, 3),
             "roofline": roof,
             "per_kernel_ms_per_step": {k: round(v / steps, 4) for k, v in k_times.items()},
+            "per_kernel_launches_per_step": {k: round(v / steps, 3) for k, v in k_launch.items()},
+            "layout_bytes_per_frame": {k[len("algorithmic_bytes_"):]: int(v) for k, v in st.items() if k.startswith("algorithmic_bytes_")},
             "rays_per_frame": {"traced_all_ranks": int(P["rays_traced_frame"]), "reference_equivalent_all_ranks": int(P["rays_ref_equiv_frame"]),
                                "primary_listed_all_ranks": int(P["rays_listed_frame"]), "primary_never_generated_all_ranks": int(P["rays_culled_frame"]),
-                               "shadow_rank0": int(st["rays_shadow"]), "reflect_rank0": int(st["rays_reflect"])},
+                               "shadow_rank0": int(st["rays_shadow"]), "reflect_rank0": int(st["rays_reflect"]),
+                               "shadow_primary_rank0": int(st["rays_shadow_primary"]), "reflect_primary_rank0": int(st["rays_reflect_primary"])},
             "workloads": {k: summary(r) for k, r in results.items()},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -88,6 +88,10 @@ struct Mesh {
 //   [24], [25]     = int32 child[4]: >= 0 wide node, < 0 ~leaf index, INT32_MIN empty slot (whose box is all NaN: no ray passes it)
 //   [26]           = uint32 axes: split axis of the binary node | of its left child << 8 | of its right child << 16
 constexpr int kWideNodeDoubles = 28;
+// The reference-shaped BSP of a `bspMesh depth` primitive (root >= 0) has a two-levels-at-a-time form as well, for the same walk:
+// 40 doubles = five BspNode slots of the node array per branch (ft_scene.cpp, widen_bsp): the boxes of the branch's two children,
+// those of its four grandchildren in the reference's visiting order (right-right, right-left, left-right, left-left), int32 child[4]
+// at doubles 36..37 (>= 0 slot of the grandchild's record, < 0 ~leaf, INT32_MIN empty).  mesh_wide[mesh] = slot of the root's record.
 struct BspNode {           // 64 bytes; BspMesh.fs:12-19 (also used for BVH nodes)
     double bmin[3], bmax[3];
     int32_t left, right;   // >= 0 branch node; < 0: ~leaf index

@@ -297,7 +297,7 @@ FT_DEV bool tri_hit_wave(cdp T, const Ray& r, bool live, double& t_out) {
 }
 
 // BoundingBox.intersects (BoundingBox.fs:32-58), inverse direction precomputed per ray.
-FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz, double* entry = nullptr) {
+FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz, double* entry = nullptr, double* exit = nullptr) {
     struct { double bmin[3], bmax[3]; } n = {{nd[0], nd[1], nd[2]}, {nd[3], nd[4], nd[5]}};
     const bool nx = ivx < 0.0, ny = ivy < 0.0, nz = ivz < 0.0;
     double tmin = ((nx ? n.bmax[0] : n.bmin[0]) - r.ox) * ivx;
@@ -313,6 +313,7 @@ FT_DEV bool aabb_hit(cdp nd, const Ray& r, double ivx, double ivy, double ivz, d
     tmin = fs_max(tzmin, tmin);
     tmax = fs_min(tzmax, tmax);
     if (entry) *entry = tmin;
+    if (exit) *exit = tmax;
     return (tmin < __builtin_inf()) && (tmax > -__builtin_inf());
 }
 
@@ -520,7 +521,8 @@ FT_DEV void mesh_bvh_query(const Scene& S, int32_t bvh_root, const Ray& r, Query
 // Closest / any-hit over a reference-shaped BSP tree (BspMesh.fs:67-76).  Nodes are visited in the reference's
 // order (right subtree, then left; leaf triangles in list order), so "strictly smaller t wins" reproduces the
 // stable sort; a node is entered iff the reference's own box test passes AND the box can still hold a usable
-// hit (its entry distance is not beyond the current bound, with a margin far above the rounding of either side).
+// hit (its entry distance is not beyond the current bound, with a margin far above the rounding of either side, and it does not
+// lie wholly behind the ray's origin: a triangle hit needs t > 1e-7, Triangle.fs:62, and the sign of a computed distance is exact).
 // PACKET = the wave walks the tree together (uniform stack in the lanes of a VGPR, scalar loads).
 template <bool ANY, bool PACKET>
 FT_DEV void mesh_bsp_query(const Scene& S, int32_t root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit, int32_t* stack) {
@@ -537,8 +539,8 @@ FT_DEV void mesh_bsp_query(const Scene& S, int32_t root, const Ray& r, Query<ANY
             cur = __builtin_amdgcn_readfirstlane(cur);
             if (cur >= 0) {
                 cdp nd = S.nodes + 8ull * (uint32_t)cur;
-                double entry = 0.0;
-                const bool enter = alive && aabb_hit(nd, r, ivx, ivy, ivz, &entry) && !(entry > bound * (1.0 + 1e-12) + 1e-12);
+                double entry = 0.0, exit = 0.0;
+                const bool enter = alive && aabb_hit(nd, r, ivx, ivy, ivz, &entry, &exit) && !(entry > bound * (1.0 + 1e-12) + 1e-12) && !(exit < 0.0);
                 if (__any(enter)) {
                     cip ch = reinterpret_cast<cip>(nd + 6);
                     const int left = ch[0];
@@ -564,8 +566,8 @@ FT_DEV void mesh_bsp_query(const Scene& S, int32_t root, const Ray& r, Query<ANY
             if (!__any(cur != kDone)) break;
             while (cur >= 0) {
                 cdp nd = S.nodes + 8ull * (uint32_t)cur;
-                double entry = 0.0;
-                if (aabb_hit(nd, r, ivx, ivy, ivz, &entry) && !(entry > bound * (1.0 + 1e-12) + 1e-12)) {
+                double entry = 0.0, exit = 0.0;
+                if (aabb_hit(nd, r, ivx, ivy, ivz, &entry, &exit) && !(entry > bound * (1.0 + 1e-12) + 1e-12) && !(exit < 0.0)) {
                     cip ch = reinterpret_cast<cip>(nd + 6); stack[sp * kBlock] = ch[0]; ++sp; cur = ch[1];
                 } else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
                 else cur = kDone;
@@ -583,6 +585,91 @@ FT_DEV void mesh_bsp_query(const Scene& S, int32_t root, const Ray& r, Query<ANY
         }
     }
     if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
+}
+
+// The reference-shaped BSP walked by a COHERENT wavefront two levels at a time.  The host (ft_scene.cpp, widen_bsp) collapses a
+// branch N and its two children into one 40-double record in the node array:
+//   [0..5] box of N's RIGHT child R, [6..11] of its LEFT child L; [12..35] boxes of the grandchildren in the reference's visiting
+//   order RR, RL, LR, LL (BspMesh.fs:73-75: right before left); [36..37] int32 child[4]: >= 0 the 64-byte unit of that grandchild's
+//   own record, < 0 ~leaf, INT32_MIN empty (all-NaN box).  A child of N that is a leaf takes the first slot of its half.
+// Branch boxes are the reference's own (BspMesh.fs:49) and are tested with the reference's arithmetic, (b - o) * (1 / d) per plane
+// (BoundingBox.fs:41-56); a grandchild is entered by a lane only if its parent's box passes too, so the intermediate node gates its
+// children exactly as the recursion does.  Leaves carry no box in the reference (BspMesh.fs:71); theirs is the inflated bound of their
+// triangles, which can only reject a leaf none of whose triangles the ray can hit.  Williams' test decides on NaN (0 * inf: a zero
+// direction component, origin on a slab plane) by falling through its comparisons; with every direction component of every live lane
+// comfortably non-zero no NaN or infinity can arise and the test is max(entries) <= min(exits), which is what runs here - a wave with
+// such a lane returns false and takes the one-node-at-a-time walk above.  Children are visited in the reference's order, so "strictly
+// smaller t wins" still reproduces the stable sort; the pushes are static (LL, LR, RL; RR is taken directly).
+template <bool ANY>
+FT_DEV bool mesh_bsp_packet(const Scene& S, int32_t root, int32_t wide_root, const Ray& r, Query<ANY>& q, uint32_t leaf, bool lit) {
+    bool alive = q.active && !(ANY && q.blocked);
+    if (!__any(alive)) return true;
+    const double adx = fabs(r.dx), ady = fabs(r.dy), adz = fabs(r.dz);
+    if (__any(alive && !(adx >= 1e-280 && ady >= 1e-280 && adz >= 1e-280 && adx < 1e280 && ady < 1e280 && adz < 1e280))) return false;
+    // dead lanes walk along with a harmless ray: no overflow, no NaN, and reach = -inf keeps them out of every decision
+    const double ivx = alive ? 1.0 / r.dx : 1.0, ivy = alive ? 1.0 / r.dy : 1.0, ivz = alive ? 1.0 / r.dz : 1.0;
+    const double ox = alive ? r.ox : 0.0, oy = alive ? r.oy : 0.0, oz = alive ? r.oz : 0.0;
+    double bound = ANY ? q.max_dist : q.best_t;                    // a hit at t >= bound cannot change the query's result
+    auto reach_of = [](double b) { const double m = b * (1.0 + 1e-12) + 1e-12; return m != m ? __builtin_inf() : m; };   // how far a box may begin and still matter
+    double reach = alive ? reach_of(bound) : -__builtin_inf();
+    // entry / exit distances of a box by the reference's arithmetic
+#define FT_SLAB(bx, tmin, tmax) \
+    double tmin, tmax; { double t0 = ((bx)[0] - ox) * ivx, t1 = ((bx)[3] - ox) * ivx; tmin = fmin(t0, t1); tmax = fmax(t0, t1); \
+      t0 = ((bx)[1] - oy) * ivy; t1 = ((bx)[4] - oy) * ivy; tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1)); \
+      t0 = ((bx)[2] - oz) * ivz; t1 = ((bx)[5] - oz) * ivz; tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1)); }
+#define FT_ENTERED(tmin, tmax) (__builtin_amdgcn_ballot_w64(tmax >= fmax(tmin, 0.0)) & __builtin_amdgcn_ballot_w64(tmin <= reach))
+    {   // the root's own box (its parent's record would have held it)
+        cdp nd = S.nodes + 8ull * (uint32_t)root;
+        FT_SLAB(nd, tmin, tmax);
+        const bool in = (tmax >= fmax(tmin, 0.0)) & (tmin <= reach);
+        alive = alive & in; reach = in ? reach : -__builtin_inf();
+        if (!__any(alive)) return true;
+    }
+    uint32_t best_tri = 0u;
+    bool found = false;
+    int stack_lanes = 0, sp = 0, cur = wide_root;
+    for (;;) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        sp = __builtin_amdgcn_readfirstlane(sp);
+        if (cur >= 0) {
+            cdp nd = S.nodes + 8ull * (uint32_t)cur;
+            const int32_t ch[4] = {reinterpret_cast<cip>(nd + 36)[0], reinterpret_cast<cip>(nd + 36)[1], reinterpret_cast<cip>(nd + 36)[2], reinterpret_cast<cip>(nd + 36)[3]};
+            unsigned long long half[2], m[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { FT_SLAB(nd + 6 * h, tmin, tmax); half[h] = FT_ENTERED(tmin, tmax); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { FT_SLAB(nd + 12 + 6 * c, tmin, tmax); m[c] = FT_ENTERED(tmin, tmax) & half[c >> 1]; }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#define FT_PUSH(c) asm("s_mov_b32 m0, %1\n\tv_writelane_b32 %0, %2, m0\n\ts_cmp_lg_u64 %3, 0\n\ts_addc_u32 %1, %1, 0" : "+v"(stack_lanes), "+s"(sp) : "s"(ch[c]), "s"(m[c]) : "m0", "scc")
+            FT_PUSH(3); FT_PUSH(2); FT_PUSH(1);
+#undef FT_PUSH
+#pragma clang diagnostic pop
+            if (m[0]) { cur = ch[0]; continue; }
+        } else {
+            const uint32_t first = S.bsp_leaves[2 * (~cur)], count = S.bsp_leaves[2 * (~cur) + 1];
+            for (uint32_t k = 0; k < count; ++k) {                 // list order; wave-uniform: scalar loads
+                double t = 0.0;
+                const bool h = tri_hit_wave(S.tris + 9ull * (first + k), r, alive, t);
+                if (ANY) {
+                    const bool b = h & (t < bound);
+                    q.blocked = q.blocked | b; alive = alive & !b; reach = b ? -__builtin_inf() : reach;
+                } else if (__any(h)) {
+                    const bool nearer = h & (t < bound);
+                    bound = nearer ? t : bound; best_tri = nearer ? first + k : best_tri; found = found | nearer;
+                    reach = nearer ? reach_of(t) : reach;
+                }
+            }
+            if (ANY) { if (!__any(alive)) break; }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = __builtin_amdgcn_readlane(stack_lanes, sp);
+    }
+#undef FT_SLAB
+#undef FT_ENTERED
+    if (!ANY && found) q.hit(bound, leaf, best_tri, lit);
+    return true;
 }
 
 // The same query for a COHERENT wavefront (primary rays of one 8x8 pixel block and their shadow rays):
@@ -896,8 +983,10 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                     if (bsp_root >= 0) {
                         Ray rm;
                         to_model(S.leaves + 16ull * arg, (H.flags & LF_XFORM) != 0, r, rm);
-                        if (coherent) mesh_bsp_query<ANY, true>(S, bsp_root, rm, q, arg, lit, stack);
-                        else mesh_bsp_query<ANY, false>(S, bsp_root, rm, q, arg, lit, stack);
+                        if (coherent) {
+                            const int32_t wide_root = S.mesh_wide[H.mesh];     // the tree two levels at a time (none: deeper than the packet's stack)
+                            if (wide_root == INT32_MIN || !mesh_bsp_packet<ANY>(S, bsp_root, wide_root, rm, q, arg, lit)) mesh_bsp_query<ANY, true>(S, bsp_root, rm, q, arg, lit, stack);
+                        } else mesh_bsp_query<ANY, false>(S, bsp_root, rm, q, arg, lit, stack);
                         break;
                     }
                 }

@@ -631,6 +631,56 @@ struct BspBuilder {
         return bvh_build(ts, boxes, idx, 0, ts.size(), first_global, 1e-7 * extent + 1e-300, 0);
     }
 
+    // The reference-shaped BSP two levels at a time, for the packet walk of coherent wavefronts (ft_kernels.hip, mesh_bsp_packet):
+    // branch n and its two children become one record of 40 doubles = five 64-byte units of the node array,
+    //   [0..5] box of the RIGHT child, [6..11] of the LEFT child, [12..35] boxes of the grandchildren in the reference's visiting
+    //   order right-right, right-left, left-right, left-left (BspMesh.fs:73-75), [36..37] int32 child[4]: >= 0 the unit of that
+    //   grandchild's own record, < 0 ~leaf, INT32_MIN empty (all-NaN box: no comparison passes it).
+    // Branch boxes are BspMesh.compile's own (BspMesh.fs:49), untouched.  A leaf has no box in the reference (BspMesh.fs:71): it gets
+    // the bound of its triangles, inflated, which can only turn away rays that cannot hit any of them.  A child of n that is a leaf
+    // takes the first slot of its half, with its box in the half's slot too.
+    static constexpr int kBspWideUnits = 5;
+    Box bsp_leaf_box(int32_t leaf_ref, double pad) const {
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        const ftd::BspLeaf& L = out.bsp_leaves[(size_t)~leaf_ref];
+        if (L.n_tris == 0) return Box{{nan, nan, nan}, {nan, nan, nan}};       // an empty leaf is never worth entering
+        Box b{{1e308, 1e308, 1e308}, {-1e308, -1e308, -1e308}};
+        for (uint32_t k = 0; k < L.n_tris; ++k) {
+            const double* T = &out.tris[9 * (size_t)(L.first_tri + k)];
+            for (int v = 0; v < 3; ++v) for (int a = 0; a < 3; ++a) {
+                const double q = T[a] + (v == 1 ? T[3 + a] : v == 2 ? T[6 + a] : 0.0);
+                b.lo[a] = std::min(b.lo[a], q); b.hi[a] = std::max(b.hi[a], q);
+            }
+        }
+        for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; }
+        return b;
+    }
+    int32_t widen_bsp(int32_t n, double pad) {
+        const size_t unit = out.nodes.size();
+        out.nodes.resize(unit + kBspWideUnits, ftd::BspNode{});
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        double rec[40];
+        for (double& v : rec) v = nan;
+        int32_t child[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+        auto put = [&](int slot, const Box& b) { for (int a = 0; a < 3; ++a) { rec[6 * slot + a] = b.lo[a]; rec[6 * slot + 3 + a] = b.hi[a]; } };
+        auto exact = [&](int32_t c) { const ftd::BspNode& nd = out.nodes[(size_t)c]; return Box{{nd.bmin[0], nd.bmin[1], nd.bmin[2]}, {nd.bmax[0], nd.bmax[1], nd.bmax[2]}}; };
+        const int32_t halves[2] = {out.nodes[(size_t)n].right, out.nodes[(size_t)n].left};   // right before left
+        for (int h = 0; h < 2; ++h) {
+            const int32_t c = halves[h];
+            if (c < 0) { const Box b = bsp_leaf_box(c, pad); put(h, b); put(2 + 2 * h, b); child[2 * h] = c; continue; }
+            put(h, exact(c));
+            const int32_t gk[2] = {out.nodes[(size_t)c].right, out.nodes[(size_t)c].left};
+            for (int k = 0; k < 2; ++k) {
+                if (gk[k] < 0) { put(2 + 2 * h + k, bsp_leaf_box(gk[k], pad)); child[2 * h + k] = gk[k]; }
+                else { put(2 + 2 * h + k, exact(gk[k])); child[2 * h + k] = widen_bsp(gk[k], pad); }
+            }
+        }
+        std::memcpy(rec + 36, child, sizeof child);
+        rec[38] = rec[39] = 0.0;
+        std::memcpy(reinterpret_cast<double*>(&out.nodes[unit]), rec, sizeof rec);
+        return (int32_t)unit;
+    }
+
     // BspMesh.compile (BspMesh.fs:51-65); returns a child reference.
     int32_t compile(int depth_left, const std::vector<Tri3>& ts, uint32_t level) {
         if (failed) return -1;
@@ -709,6 +759,16 @@ int32_t build_bsp(const double* tris_abc, int64_t n_tris, int32_t depth, FlatSce
         if (mesh.bvh_root >= 0 && (int32_t)b.bvh_depth + 1 > out.stack_capacity) out.stack_capacity = (int32_t)b.bvh_depth + 1;
     }
     if (deferred) return FT_OK;
+    if (root >= 0 && b.max_depth <= 40) {                                       // a real tree: its two-levels-at-a-time form (3 stack entries per wide level, 64 at most)
+        const ftd::BspNode& top = out.nodes[(size_t)root];
+        double extent = 0.0;
+        for (int a = 0; a < 3; ++a) extent = std::max(extent, std::max(std::fabs(top.bmin[a]), std::fabs(top.bmax[a])));
+        if (extent < 1e300) {
+            const size_t n0 = out.nodes.size();
+            wide_root = b.widen_bsp(root, 1e-7 * extent + 1e-300);
+            out.bvh_nodes += (int64_t)(out.nodes.size() - n0);                  // not part of BspMesh.compile's tree
+        }
+    }
     out.mesh_wide.push_back(wide_root);
     {   // <= 64 boxes that together hold every triangle of the mesh: one level of the binary tree (BVH of a top-level Leaf, or the BSP itself)
         const int32_t top = root < 0 ? mesh.bvh_root : root;
