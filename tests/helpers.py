@@ -81,12 +81,17 @@ def build_described_scene(b, objects, lights):
     def node(o):
         if "csg" in o:
             n = getattr(b, o["csg"])(node(o["a"]), node(o["b"]))
+        elif "triangle" in o:
+            n = b.triangle(*o["triangle"])
         else:
             n = b.primitive(PRIMS[o["prim"]])
         if o.get("xf"):
             n = b.transform([(t[0], t[1], deg(t[2])) if t[0] == "rotate" else (t[0], t[1]) for t in o["xf"]], n)
         if "material" in o:
             n = b.material(n, **o["material"])
+        if "texture" in o:                                    # Scene.Texture: a grid under its uv functions, outermost first (Scene.fs:47-53, 68-75)
+            ops = [(0.0, t[1], t[2]) if t[0] == "scale" else (1.0, deg(t[1]), 0.0) for t in o["texture"]["ops"]]
+            n = b.texture_grid(o["texture"]["grid"][0], o["texture"]["grid"][1], ops, n)
         if o.get("ignore_light"):
             n = b.ignore_light(n)
         return n
@@ -110,6 +115,34 @@ def check_shading_case(b, case, rtol=1e-9):
     assert np.array_equal(np.isnan(got), np.isnan(want)), f"{case['name']}: NaN pattern {got} vs {want}"
     ok = np.isclose(got, want, rtol=rtol, atol=1e-15) | np.isnan(want)
     assert ok.all(), f"{case['name']}: got {got.tolist()}, hand-derived {want.tolist()} ({case['cites']})"
+
+
+def check_closest_case(b, case):
+    """One ray against the case's scene through Scene.intersect + closest (no slightOffset): hit, t, p, n against the hand-derived values."""
+    build_described_scene(b, case["objects"], [])
+    hit, t, p, n, _ = b.closest([case["o"]], [case["d"]])
+    assert bool(hit[0]) == case["hit"], f"{case['name']} ({case['cites']})"
+    if case["hit"]:
+        assert abs(t[0] - case["t"]) <= 1e-12 * max(1.0, abs(case["t"])), f"{case['name']}: t {t[0]!r} vs {case['t']!r}"
+        assert np.allclose(p[0], case["p"], rtol=0, atol=case.get("p_atol", 1e-12)), f"{case['name']}: p {p[0]} vs {case['p']}"
+        assert np.allclose(n[0], case["n"], rtol=0, atol=1e-12), f"{case['name']}: n {n[0]} vs {case['n']}"
+
+
+def check_frame_case(b, case, **render_args):
+    """Render the case's tiny frame through builder `b` and compare every pixel with its hand-derived colour."""
+    build_described_scene(b, case["objects"], case["lights"])
+    c = case["camera"]
+    cam = ft.make_camera(c["o"], c["look_at"], c["up"], deg(c["fov_deg"]), c["aspect"])
+    jitter = np.array(case["jitter"], dtype=np.float64).reshape(-1, 2)
+    frame, _ = b.render(cam, case["res"][0], case["res"][1], case["spp"], jitter, **render_args)
+    want = np.array(case["frame"], dtype=np.float64)
+    assert np.allclose(frame, want, rtol=1e-12, atol=1e-15), f"{case['name']}: got {frame.tolist()}, hand-derived {want.tolist()} ({case['cites']})"
+
+
+def round3_cases(kind):
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "known_answers.json")) as f:
+        return json.load(f)["hand_derived_round3"][kind]
 
 
 def csg_pair(b, op):

@@ -56,6 +56,21 @@ def test_hand_derived_csg_tables_on_the_device(hip, golden):  # Csg.fs:19-55, 59
                 assert t[k] == pytest.approx(c["t"], abs=1e-12) and np.allclose(n[k], c["n"], atol=1e-12), (op, c["why"], t[k], n[k])
 
 
+@pytest.mark.parametrize("case", H.round3_cases("closest"), ids=lambda c: c["name"])
+def test_hand_derived_triangle_and_transformed_normals_on_the_device(hip, case):    # Triangle.fs:43-66, Transform.fs:77-87
+    H.check_closest_case(hip, case)
+
+
+@pytest.mark.parametrize("case", H.round3_cases("shading"), ids=lambda c: c["name"])
+def test_hand_derived_oren_nayar_textures_soft_shadows_on_the_device(hip, case):    # Shading.fs:24-31, 50-63; Texture.fs:8-29; Sphere.fs:6-10
+    H.check_shading_case(hip, case)
+
+
+@pytest.mark.parametrize("case", H.round3_cases("frames"), ids=lambda c: c["name"])
+def test_hand_derived_blend_and_corner_average_on_the_device(hip, case):            # Image.fs:83-89, 112-116, 125-145
+    H.check_frame_case(hip, case)
+
+
 def test_debug_colour_equals_the_rendered_pixel(hip):
     """ft_debug_colour is the frame's own shading path fed with explicit rays: the colour of the ray through a pixel centre equals
     that pixel of a 1-sample frame with a zero jitter offset (the device contracts the ray's a*b+c into FMAs, the oracle's

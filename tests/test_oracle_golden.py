@@ -162,3 +162,19 @@ def test_hand_derived_csg_tables(golden):                     # Csg.fs:19-55, 59
             assert bool(hit[k]) == c["hit"], (op, c["why"])
             if c["hit"]:
                 assert t[k] == pytest.approx(c["t"], abs=1e-12) and np.allclose(n[k], c["n"], atol=1e-12), (op, c["why"], t[k], n[k])
+
+
+# ---- round 3: closed forms for what rounds 1-2 pinned by oracle == device alone (tests/tools/derive_round3_answers.py) -------------
+@pytest.mark.parametrize("case", H.round3_cases("closest"), ids=lambda c: c["name"])
+def test_hand_derived_triangle_and_transformed_normals(case):    # Triangle.fs:43-66, Transform.fs:77-87
+    H.check_closest_case(O.Oracle(), case)
+
+
+@pytest.mark.parametrize("case", H.round3_cases("shading"), ids=lambda c: c["name"])
+def test_hand_derived_oren_nayar_textures_soft_shadows(case):    # Shading.fs:24-31, 50-63; Texture.fs:8-29; Sphere.fs:6-10
+    H.check_shading_case(O.Oracle(), case)
+
+
+@pytest.mark.parametrize("case", H.round3_cases("frames"), ids=lambda c: c["name"])
+def test_hand_derived_blend_and_corner_average(case):            # Image.fs:83-89, 112-116, 125-145
+    H.check_frame_case(O.Oracle(), case)
