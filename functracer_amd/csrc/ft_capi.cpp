@@ -195,6 +195,12 @@ int lane_fold_for(const fth::FlatScene& f) {
     }
     return 0;
 }
+// Materials only the FANCY kernel variants shade: Oren-Nayar, textures, and a specular exponent that is not a small whole number
+// (the lean variants raise to whole powers up to 64 by square-and-multiply and do not carry Math.Pow, ft_kernels.hip shade_lights).
+bool needs_fancy(const ftd::Material& m) {
+    const bool whole = m.shineyness <= 64.0 && m.shineyness == std::floor(m.shineyness);
+    return m.roughness != 0.0 || m.texture >= 0 || (m.shineyness > 0.0 && !whole) || m.shineyness != m.shineyness;
+}
 size_t lds_bytes_for(const fth::FlatScene& f) {
     const int fold = std::max(1, lane_fold_for(f));
     return (4 * (((size_t)f.csg_capacity + (size_t)fold - 1) / (size_t)fold) + (size_t)f.stack_capacity) * ftk::kBlock * 4;
@@ -480,6 +486,7 @@ static int32_t upload_scene(ft_context* c) {
     S.item_pc = c->d_item_pc.as<uint32_t>();
     S.coherent_waves = c->coherent_waves ? 1 : 0;
     S.n_simd = c->n_cu * 4;
+    S.n_hollow = f.n_hollow;
     S.n_items = (int32_t)f.item_pc.size() - 1; S.n_cull_rows = f.cull_bundle ? (int32_t)(f.cull_rows.size() / 3) : -1;
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;
@@ -797,7 +804,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
     int variant = 0;
-    for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;   // FANCY
+    for (auto& m : c->flat.materials) if (needs_fancy(m)) variant |= 1;                         // FANCY
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
     if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
     // Samples per bounce-0 wavefront (slot_at, ft_kernels.hip): 2^group_log2 samples of 64 / 2^group_log2 pixels when the sample count
@@ -1138,7 +1145,7 @@ static int32_t debug_colour(ft_context* c, const double* origins, const double* 
     FT_HIP(c, hipMemsetAsync(c->d_acc.p, 0, 3 * N * 8, c->stream));
     const size_t lds = lds_bytes_for(c->flat);
     int variant = 0;
-    for (auto& m : c->flat.materials) if (m.roughness != 0.0 || m.texture >= 0) variant |= 1;
+    for (auto& m : c->flat.materials) if (needs_fancy(m)) variant |= 1;
     for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;
     if (!c->flat.meshes.empty()) variant |= 4;
     ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_bounce(lds, variant), lds, variant};

@@ -91,7 +91,7 @@ struct Scene {
     const float* coarse_boxes;   // lane k reads box k
     cdp cull_rows;
     cup item_pc;
-    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold, n_simd;
+    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold, n_simd, n_hollow;
 };
 static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
 template <class DS> FT_DEV Scene scene_view(const DS& g) {
@@ -103,7 +103,7 @@ template <class DS> FT_DEV Scene scene_view(const DS& g) {
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig); s.wide = to_const_as(g.wide); s.mesh_wide = to_const_as(g.mesh_wide);
     s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.coarse_boxes = g.coarse_boxes; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
-    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap; s.csg_rows = g.csg_rows; s.lane_fold = g.lane_fold; s.n_simd = g.n_simd;
+    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap; s.csg_rows = g.csg_rows; s.lane_fold = g.lane_fold; s.n_simd = g.n_simd; s.n_hollow = g.n_hollow;
     return s;
 }
 struct MaterialV { double colour[3]; double roughness, reflectance, shineyness; uint32_t apply_lighting; int32_t texture; uint32_t hue_rot; };
@@ -140,6 +140,17 @@ FT_DEV double fs_max(double a, double b) { return (a != a || b != b) ? __builtin
 FT_DEV double fs_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
 
 FT_DEV uint32_t lane_id() { return __lane_id(); }
+// A wave-uniform double the compiler computed with vector instructions (a division, a conversion), moved to a scalar register
+// pair: held across the batch loop in VGPRs such values - reciprocals of the launch's counts, the number of lights as a double -
+// were what the register allocator spilled to scratch first.
+FT_DEV double uniform_f64(double v) {
+#ifdef FT_AB_NO_UNIFORM
+    return v;
+#endif
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 FT_DEV uint32_t lanes_below(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -810,7 +821,7 @@ constexpr int kSparseLanes = 8;                                     // at most t
 struct ItemMask { unsigned long long lo, hi; bool valid; };   // bit k: top-level item k may be hit by some ray of the wave (items >= 128: not covered)
 // A bundle of rays bounded by a cone: apex c (origins within rho of it), unit axis a, half-angle given by cos_t (rounded down) /
 // sin_t (rounded up); par_rows = face directions some ray of the bundle may be nearly parallel to.
-struct Cone { float ax, ay, az, cx, cy, cz, cos_t, sin_t, rho; uint32_t par_rows; };
+struct Cone { float ax, ay, az, cx, cy, cz, cos_t, sin_t, rho; uint32_t par_rows; float far; };   // far: no usable hit lies further from the apex than this (+inf: unbounded)
 // One item (8-float record: centre, radius, face-direction mask, ...) against one cone: false only when no ray inside the cone can
 // give a usable hit on the item.
 FT_DEV bool cone_may_reach(float ix, float iy, float iz, float radius, uint32_t rows, const Cone& B, float origin_mag) {
@@ -818,14 +829,18 @@ FT_DEV bool cone_may_reach(float ix, float iy, float iz, float radius, uint32_t 
     const float slack = 1e-5f * (1.0f + origin_mag + fabsf(ix) + fabsf(iy) + fabsf(iz));
     const float reach = radius * 1.0001f + B.rho + slack;          // sphere radius + origin spread + rounding slack
     const float h = vx * B.ax + vy * B.ay + vz * B.az;
-    const float w = sqrtf(fmaxf(0.0f, (vx * vx + vy * vy + vz * vz) - h * h));
+    const float v2 = vx * vx + vy * vy + vz * vz;
+    const float w = sqrtf(fmaxf(0.0f, v2 - h * h));
+    const float out_of_range = B.far + reach;                      // the whole sphere lies further from the apex than any usable hit
+    if (v2 > out_of_range * out_of_range * 1.0001f && !((rows & B.par_rows) != 0u)) return false;
     // lower bound of the distance from the centre to the cone: beyond its nearest tangent plane in front of the apex;
     // behind the apex the cone also lies within the half-space (x - apex).axis >= 0
     const float beyond = h > 0.0f ? w * B.cos_t - h * B.sin_t : fmaxf(w * B.cos_t, -h);
     return !(beyond > reach) || (rows & B.par_rows) != 0u;
 }
 // Lane k tests top-level ITEM k: bit k of the result is clear only when no ray inside the cone can give a usable hit on it.
-FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B) {
+struct SegmentEnds { float cx, cy, cz, rho; };                      // the far ends of a bundle of segments: within rho of c
+FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B, const SegmentEnds* seg = nullptr) {
     ItemMask M{~0ull, ~0ull, true};
     const float origin_mag = fabsf(B.cx) + fabsf(B.cy) + fabsf(B.cz);
     const int n_pass = S.n_items > 64 ? 2 : 1;
@@ -833,14 +848,68 @@ FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B) {
         const int item = pass * 64 + (int)lane_id();
         bool keep = true;
         if (item < S.n_items) {
-            const float* I = S.cull_items + 8 * item;
-            keep = cone_may_reach(I[0], I[1], I[2], I[3], __float_as_uint(I[4]), B, origin_mag);
+            const float* I = S.cull_items + 8 * (item + (int)opaque_zero());   // (worked out here: hoisted out of the batch loop, the address was spilled)
+            const uint32_t rows = __float_as_uint(I[4]);
+            keep = cone_may_reach(I[0], I[1], I[2], I[3], rows, B, origin_mag);
+            // A - B with B a sphere (under any transform: an ellipsoid, convex) cannot be hit between two points that both lie inside B:
+            // along such a segment the line is inside B (no B crossing), and an A crossing met while inside B is discarded by the
+            // subtract table (Csg.fs:27-33: BIntoAB, ABleaveA).  Shadow segments towards a point light all end at the light; their
+            // origins lie within `seg->rho` of seg->c.  Both must be inside B by a margin far above the float arithmetic here.
+            const uint32_t hollow = __float_as_uint(I[7]);
+            if (seg && keep && hollow != 0u && __float_as_uint(I[6]) == 0u && (rows & B.par_rows) == 0u) {
+                const float* Hm = S.cull_items + 8 * hollow;                   // 12 floats: world -> model of B (a unit sphere there), [12]: bound of its 3x3 norm
+                auto inside = [&](float x, float y, float z, float pad) {
+                    const float qx = Hm[0] * x + Hm[1] * y + Hm[2] * z + Hm[3], qy = Hm[4] * x + Hm[5] * y + Hm[6] * z + Hm[7], qz = Hm[8] * x + Hm[9] * y + Hm[10] * z + Hm[11];
+                    const float slack = 1e-5f * (1.0f + fabsf(x) + fabsf(y) + fabsf(z)) * Hm[12];
+                    return sqrtf(qx * qx + qy * qy + qz * qz) + pad * Hm[12] + slack < 0.9999f;
+                };
+                if (inside(B.cx, B.cy, B.cz, B.rho) && inside(seg->cx, seg->cy, seg->cz, seg->rho)) keep = false;
+            }
         }
         const unsigned long long km = __ballot(keep && item < S.n_items);
         if (pass == 0) M.lo = km; else M.hi = km;
     }
     if (n_pass == 1) M.hi = 0ull;
     return M;
+}
+FT_DEV float wave_max(float v) { return -wave_min(-v); }
+// Shadow rays towards a point light (Shading.fs:38-42: d = normalise (position - point), maxDistance = |position - point|): every ray
+// of the wave passes through the light, so the bundle is a cone whose APEX is the light - no origin spread to pad it with - and a
+// usable hit (0 <= t < maxDistance, Scene.fs:121) lies between the light and the ray's origin: no further from the apex than the
+// longest segment.  Items behind the light fall behind the apex, items beyond the surface patch beyond `far`.
+FT_DEV ItemMask bundle_cull_to_light(const Scene& S, const Ray& r, bool live, cdp light, double max_dist) {
+    ItemMask M{~0ull, ~0ull, false};
+    const unsigned long long lm = __ballot(live);
+    if (lm == 0ull) return M;
+    float ex = -(float)r.dx, ey = -(float)r.dy, ez = -(float)r.dz;  // from the light towards the ray's origin
+    const float l2 = ex * ex + ey * ey + ez * ez;
+    const float far_lane = (float)max_dist;
+    if (__any(live && !(l2 > 0.25f && l2 < 4.0f && far_lane < 1e30f))) return M;   // the directions are unit vectors unless the point sits on the light
+    const float inv = __builtin_amdgcn_rsqf(l2);
+    ex *= inv; ey *= inv; ez *= inv;
+    const int first = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)lm) - 1);
+    const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), first)), ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ey), first)),
+                az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez), first));
+    const float cos_t = wave_min(live ? ax * ex + ay * ey + az * ez : 1.0f) - 1e-5f;
+    if (!(cos_t > 0.3f)) return M;
+    const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f;
+    const float cx = (float)light[0], cy = (float)light[1], cz = (float)light[2];
+    const float far = wave_max(live ? far_lane : 0.0f);
+    const float rho = 1e-5f * (1.0f + fabsf(cx) + fabsf(cy) + fabsf(cz) + far);     // the float images of the light and of the directions
+    uint32_t par_rows = 0;
+    for (int k = 0; k < S.n_cull_rows; ++k) {
+        cdp Rw = S.cull_rows + 3u * (uint32_t)k;
+        if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
+    }
+    // the origins, for the items that cannot be hit between two points inside them (items_in_cone): within seg.rho of the first one
+    const float ox = (float)r.ox, oy = (float)r.oy, oz = (float)r.oz;
+    SegmentEnds seg{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox), first)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy), first)),
+                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oz), first)), 0.0f};
+    if (S.n_hollow > 0) {
+        const float dx = ox - seg.cx, dy = oy - seg.cy, dz = oz - seg.cz;
+        seg.rho = sqrtf(wave_max(live ? dx * dx + dy * dy + dz * dz : 0.0f)) * 1.0001f + 1e-5f * (1.0f + fabsf(seg.cx) + fabsf(seg.cy) + fabsf(seg.cz));
+    }
+    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, far * 1.0001f + rho}, S.n_hollow > 0 ? &seg : nullptr);
 }
 FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     ItemMask M{~0ull, ~0ull, false};
@@ -872,7 +941,7 @@ FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
         cdp Rw = S.cull_rows + 3u * (uint32_t)k;
         if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
     }
-    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows});
+    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, __builtin_inff()});
 }
 
 // Exact skip test of one top-level item (cull record C: centre, radius^2, number of face directions, the directions) for one ray.
@@ -933,12 +1002,20 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
     return M;
 }
 
+#ifdef FT_ITEM_COUNTS
+// Diagnostic build only (tools/item_counts.py): how many top-level items a wave's query evaluates.  [4 * kind + k], kind = ANY * 2 + incoherent:
+// k = 0 queries, 1 items evaluated, 2 live lanes, 3 items the mask offered (before each item's own OP_CULL).
+__device__ unsigned long long g_item_counts[16];
+#define FT_COUNT(k, v) do { if (lane_id() == 0) atomicAdd(&g_item_counts[4 * ((ANY ? 2 : 0) + (coherent ? 0 : 1)) + (k)], (unsigned long long)(v)); } while (0)
+#else
+#define FT_COUNT(k, v) do { } while (0)
+#endif
 // ---------------------------------------------------------------------------------------------
 // The scene program interpreter: Scene.intersect (Scene.fs:67-104) + closest / lightIsBocked.
 // MESH = false compiles the triangle / BSP / BVH code out: scenes without meshes then run kernels with
 // markedly fewer registers.
 template <bool ANY, bool MESH>
-FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow, bool coherent = false) {
+FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bool& overflow, bool coherent = false, cdp to_light = nullptr) {
     HitList L;
     L.init(lds, S.csg_cap, S.csg_rows, S.lane_fold);
     int32_t* stack = reinterpret_cast<int32_t*>(lds + 4 * S.csg_rows * kBlock) + threadIdx.x;
@@ -946,9 +1023,10 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
     // go to the earlier one); everything else walks the whole program, every item behind its own OP_CULL.
     ItemMask IM{~0ull, ~0ull, false};
     const bool live = ANY ? (q.active && !q.blocked) : q.active;
-    if (coherent) IM = bundle_cull(S, r, live);
+    if (coherent) IM = (ANY && to_light && S.n_items >= 3 && S.n_cull_rows >= 0) ? bundle_cull_to_light(S, r, live, to_light, q.max_dist) : bundle_cull(S, r, live);
     const bool exact_mask = !IM.valid;                             // the bundle bounded nothing (or was not tried): per-ray tests up front
     if (exact_mask) IM = exact_cull(S, r, live);
+    FT_COUNT(0, 1); FT_COUNT(2, __popcll(__ballot(live))); FT_COUNT(3, IM.valid ? __popcll(IM.lo) + __popcll(IM.hi) : S.n_items);
     uint32_t item_end = 0xFFFFFFFFu;
     for (uint32_t pc = 0;; ++pc) {
         if (IM.valid && (item_end == 0xFFFFFFFFu || pc >= item_end)) {
@@ -970,6 +1048,7 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                 const LeafHead H = leaf_head(S, arg);
                 const bool lit = (H.flags & LF_LIT) != 0;
                 if (ANY && !lit) break;                            // an unlit object never blocks light (Scene.fs:121)
+                FT_COUNT(1, 1);
                 if (MESH && H.kind == LK_MESH) {
                     const int32_t bvh = S.meshes[4 * H.mesh + 3];
                     if (bvh >= 0) {
@@ -1011,6 +1090,7 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
             case OP_CSG_PAIR: {
                 // Csg.constructedSolid (Csg.fs:74-94) over two bare primitives with the hit lists in registers.  The
                 // stable sort of [A hits; B hits] by t is the merge of the two (stably sorted) operands with ties to A.
+                FT_COUNT(1, 1);
                 const uint32_t leaf_a = S.program[pc + 1], wb = S.program[pc + 2];
                 const uint32_t leaf_b = wb & ID_LEAF_MASK, cop = (wb >> 24) & 3u;
                 const bool fold = ((wb >> 26) & 1u) != 0;
@@ -1196,7 +1276,11 @@ FT_DEV void textured_colour(const Scene& S, const MaterialV& mat, double u, doub
 struct BatchCursor {
     uint32_t* ctr; uint32_t cls;
     FT_DEV BatchCursor(uint32_t* counters) {
+#ifdef FT_AB_NO_UNIFORM_WAVE
         const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+#else
+        const uint32_t wave = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));   // uniform: the cursor's address stays scalar
+#endif
         cls = wave % (uint32_t)kWorkGroups;
         ctr = counters + 16u * cls;
     }
@@ -1277,7 +1361,7 @@ FT_DEV Pix pix_count(PrimaryArg g) {
         n = n_active > first ? (n_active - first < cap ? n_active - first : cap) : 0u;
     }
     const uint32_t nb = n >> 6;                                     // one division per batch is cheaper than a launch that stores the reciprocals
-    return {n, 1.0 / (double)n, nb, 1.0 / (double)(nb ? nb : 1u), (n & 63u) ? 0u : (uint32_t)g->group_log2};   // grouped numbering needs whole blocks (k_resolve: the same rule)
+    return {n, uniform_f64(1.0 / (double)n), nb, uniform_f64(1.0 / (double)(nb ? nb : 1u)), (n & 63u) ? 0u : (uint32_t)g->group_log2};   // grouped numbering needs whole blocks (k_resolve: the same rule)
 }
 
 // How a chunk's samples are numbered.  A slot is a sample's place in the colour planes (acc) and the unit a wavefront's lane takes.
@@ -1375,7 +1459,7 @@ FT_DEV void light_visibility(const Scene& S, const Surface& sf, bool lit, unsign
                 sr = {sox, soy, soz, -lp[0], -lp[1], -lp[2]};
                 q.max_dist = 1.7976931348623157e308;           // System.Double.MaxValue
             }
-            if (__any(lit)) trace<true, MESH>(S, sr, q, lds, overflow, coherent);
+            if (__any(lit)) trace<true, MESH>(S, sr, q, lds, overflow, coherent, kind == LT_POINT ? lp : nullptr);
             n_shadow_wave += (unsigned long long)__popcll(__ballot(lit));
             occluded = q.blocked ? 1ull : 0ull;
         }
@@ -1430,7 +1514,15 @@ FT_DEV void shade_lights(const Scene& S, const Surface& sf, const MaterialV& mat
                     for (uint32_t bit = 0; __any((e >> bit) != 0u); ++bit) { if ((e >> bit) & 1u) pw *= b; b *= b; }
                     if (wants && small_int) si = pw;
                 }
-                if (__any(wants && !small_int)) { const double pw = pow(base, mat.shineyness); if (wants && !small_int) si = pw; }
+                // Math.Pow proper only exists in the FANCY variants (the host routes every scene with such an exponent there): inlined into the
+                // lean kernels its seventeen polynomial constants were hoisted out of the batch loop and spilled - 136 bytes of scratch per lane,
+                // stored by every wave of every launch before its first batch
+#ifdef FT_AB_POW_ALL
+                constexpr bool kPow = true;
+#else
+                constexpr bool kPow = FANCY;
+#endif
+                if (kPow) { if (__any(wants && !small_int)) { const double pw = pow(base, mat.shineyness); if (wants && !small_int) si = pw; } }
             }
             if (!(mat.shineyness <= 0.0 || si <= 0.0)) { fr = lcr * si; fg = lcg * si; fb = lcb * si; }
         }
@@ -1552,7 +1644,7 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
                 const double k2 = 2.0 * dot3(rv.dx, rv.dy, rv.dz, sf.n.x, sf.n.y, sf.n.z);
                 next.ox[o] = sf.p.x; next.oy[o] = sf.p.y; next.oz[o] = sf.p.z;
                 next.dx[o] = rv.dx - k2 * sf.n.x; next.dy[o] = rv.dy - k2 * sf.n.y; next.dz[o] = rv.dz - k2 * sf.n.z;
-                next.w[o] = 1.0 * (mat.reflectance * (double)n_lights);
+                next.w[o] = 1.0 * (mat.reflectance * uniform_f64((double)n_lights));
                 next.slot[o] = i;
             }
             n_refl_wave += cnt;
@@ -1573,7 +1665,7 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
     wave_add(&mine->hits_primary, n_hit_wave);
     wave_add(&mine->csg_overflow, n_ovf_wave);
     // what the F# recursion would trace (Shading.fs:109-139), depth 0
-    wave_add(&mine->ref_equiv, (double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave);
+    wave_add(&mine->ref_equiv, uniform_f64((double)fresh(K)->S.shadow_rays_per_hit * (double)n_hit_wave + (double)n_lights * (double)n_refl_wave));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1612,7 +1704,9 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
     unsigned long long n_shadow_wave = 0, n_refl_wave = 0, n_ovf_wave = 0, n_hit_wave = 0;
     double ref_wave = 0.0;
     double mult0 = 1.0;                                             // copies of a ray of this level in the F# recursion (Shading.fs:109-139): L^bounce, exactly
-    for (int k = 0; k < bounce; ++k) mult0 *= (double)n_lights;
+    const double lights_f = uniform_f64((double)n_lights);         // wave-uniform doubles live in scalar registers (uniform_f64)
+    for (int k = 0; k < bounce; ++k) mult0 *= lights_f;
+    mult0 = uniform_f64(mult0);
     const uint32_t B = batch_lanes_for(n, S.lane_fold, S.n_simd);
     const uint32_t n_batches = (n + B - 1) / B;
     BatchCursor cursor(&cc->work_trace[bounce][0]);
@@ -1626,7 +1720,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
             r = {rays.ox[i], rays.oy[i], rays.oz[i], rays.dx[i], rays.dy[i], rays.dz[i]}; w = rays.w[i]; slot = rays.slot[i];
         }
         double mult = mult0;
-        for (int depth = bounce;; ++depth, mult *= (double)n_lights) {   // one pass, unless this launch follows its rays to the end
+        for (int depth = bounce;; ++depth, mult = uniform_f64(mult * lights_f)) {   // one pass, unless this launch follows its rays to the end
             // ---- closest hit; the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
             const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
             Query<false> q;
@@ -1664,7 +1758,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
             const uint32_t cnt = (uint32_t)__popcll(m);
             n_refl_wave += cnt;
             n_hit_wave += (unsigned long long)__popcll(hit_mask);
-            ref_wave += mult * ((double)K2->S.shadow_rays_per_hit * (double)__popcll(hit_mask) + (double)n_lights * (double)cnt);
+            ref_wave = uniform_f64(ref_wave + mult * ((double)K2->S.shadow_rays_per_hit * (double)__popcll(hit_mask) + lights_f * (double)cnt));
             const double k2 = 2.0 * dot3(r.dx, r.dy, r.dz, sf.n.x, sf.n.y, sf.n.z);
             if (!follow) {                                          // the level's reflection rays, compacted into the other buffer
                 uint32_t dst = 0;
@@ -1675,7 +1769,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
                     const FT_CONST RayBuf& next = K2->next;
                     next.ox[o] = sf.p.x; next.oy[o] = sf.p.y; next.oz[o] = sf.p.z;
                     next.dx[o] = r.dx - k2 * sf.n.x; next.dy[o] = r.dy - k2 * sf.n.y; next.dz[o] = r.dz - k2 * sf.n.z;
-                    next.w[o] = w * (mat.reflectance * (double)n_lights);
+                    next.w[o] = w * (mat.reflectance * lights_f);
                     next.slot[o] = slot;
                 }
                 break;
@@ -1684,7 +1778,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
             if (lane_id() == 0) atomicAdd(&K2->fc->cc.n_rays[depth + 1], cnt);   // counted all the same: the host sizes the next frame's launches from these
             if (spawn) {                                            // followed in registers: same ray, same weight as the queued one would carry
                 r = {sf.p.x, sf.p.y, sf.p.z, r.dx - k2 * sf.n.x, r.dy - k2 * sf.n.y, r.dz - k2 * sf.n.z};
-                w = w * (mat.reflectance * (double)n_lights);
+                w = w * (mat.reflectance * lights_f);
             }
             alive = spawn;
         }
@@ -1783,7 +1877,7 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify(ClassifyArgs) {
     }
     const float cox = (float)g->cam.o[0], coy = (float)g->cam.o[1], coz = (float)g->cam.o[2];
     const float origin_mag = fabsf(cox) + fabsf(coy) + fabsf(coz);
-    const Cone B{ax, ay, az, cox, coy, coz, cos_t, sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f, 1e-5f * (1.0f + origin_mag), par_rows};
+    const Cone B{ax, ay, az, cox, coy, coz, cos_t, sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f, 1e-5f * (1.0f + origin_mag), par_rows, __builtin_inff()};
     bool keep = !bounded;
     for (int item = 0; item < S.n_items; ++item) {                  // wave-uniform: the item record comes through scalar loads
         if (!__any(!keep)) break;
@@ -2160,6 +2254,13 @@ void launch_resolve(const Launch& L, const ResolveArgs& a) {
     const int cus = L.grid / 8;
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, cus * resident)), dim3(kBlock), 0, L.stream, a);
 }
+#ifdef FT_ITEM_COUNTS
+extern "C" int ft_debug_item_counts(unsigned long long out[16], int reset) {
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_item_counts), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { const unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_item_counts), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 void launch_report(const Launch& L, FrameCounters* fc, FrameReport* report) { hipLaunchKernelGGL(k_report, dim3(1), dim3(kBlock), 0, L.stream, fc, report); }
 void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba) {
     hipLaunchKernelGGL(k_resolve_corner, dim3(blocks_for(w * h, L.grid * 4)), dim3(kBlock), 0, L.stream, acc, acc_stride, w, h, out_index, out_rgb, out_rgba);

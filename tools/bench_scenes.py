@@ -12,7 +12,13 @@ CASES = [("bunny", 16), ("bunny", 4), ("hollow-sphere", 1), ("hollow-sphere", 16
          ("bunny-bsp12", 16), ("bunny-full-bsp12", 16), ("sample-det", 16), ("moon", 16), ("repeat", 4)]
 out = {}
 ctx = ft.Context(0)
+for kv in filter(None, os.environ.get("FT_OPTS", "").split(",")):      # FT_OPTS="coherent_waves=0,follow_below=2048": A/B runs
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
+only = set(filter(None, os.environ.get("FT_SCENES", "").split(",")))   # FT_SCENES="bunny,hollow-sphere": a subset
 for name, spp in CASES:
+    if only and name not in only:
+        continue
     path = os.path.join(R, "scenes", name + ".scene")
     if name == "bunny-full-bsp12" and not os.path.exists(os.path.join(R, "scenes", "meshes", "bunny_synth_full.ply")):
         continue
