@@ -486,7 +486,6 @@ static int32_t upload_scene(ft_context* c) {
     S.item_pc = c->d_item_pc.as<uint32_t>();
     S.coherent_waves = c->coherent_waves ? 1 : 0;
     S.n_simd = c->n_cu * 4;
-    S.n_hollow = f.n_hollow;
     S.n_items = (int32_t)f.item_pc.size() - 1; S.n_cull_rows = f.cull_bundle ? (int32_t)(f.cull_rows.size() / 3) : -1;
     S.n_leaves = (int32_t)f.leaves.size(); S.n_lights = (int32_t)f.lights.size();
     S.csg_cap = f.csg_capacity; S.stack_cap = f.stack_capacity;

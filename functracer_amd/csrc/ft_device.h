@@ -29,8 +29,7 @@ struct DevScene {
     const double* wide;            // 28 doubles per 4-wide BVH node (ft_flat.h)
     const int32_t* mesh_wide;      // per mesh: root of its 4-wide BVH or INT32_MIN
     const uint8_t* tex_pixels;     // Rgb24 rows of the image textures (ftd::Texture::pixel_base indexes into it)
-    const float* cull_items;       // 8 floats per top-level item (centre, radius, row mask; bare meshes: + first coarse box, count, leaf; A - sphere: [7] = where
-                                   // B's 16-float record starts, in units of 8 floats); the B records follow the item records
+    const float* cull_items;       // 8 floats per top-level item (centre, radius, row mask; bare meshes: + first coarse box, count, leaf)
     const float* coarse_boxes;     // 6 floats per box: model-space boxes that cover a mesh (k_classify)
     const uint32_t* item_pc;       // n_items + 1 program counters: where each top-level item starts (last: the OP_END word)
     const double* cull_rows;       // 3 per distinct parallel-sensitive direction
@@ -39,7 +38,6 @@ struct DevScene {
     int32_t n_items, n_cull_rows;  // n_cull_rows < 0: pre-test disabled
     int32_t csg_rows, lane_fold;   // LDS rows per hit-list column and lanes folded together (see HitList): csg_cap <= csg_rows * lane_fold
     int32_t n_simd;                // SIMDs of the device (CUs x 4): how far few rays are spread (batch_lanes_for)
-    int32_t n_hollow;              // top-level items of the form A - sphere (records behind the item records of cull_items, see items_in_cone)
     int32_t coherent_waves;        // 1 (default): bounce-0 wavefronts use the bundle paths (cone cull, packet traversal); 0: every wave is treated as incoherent (diagnostic)   // sum over lights of the shadow rays the reference casts per hit
 };
 

@@ -91,7 +91,7 @@ struct Scene {
     const float* coarse_boxes;   // lane k reads box k
     cdp cull_rows;
     cup item_pc;
-    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold, n_simd, n_hollow;
+    int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold, n_simd;
 };
 static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
 template <class DS> FT_DEV Scene scene_view(const DS& g) {
@@ -103,7 +103,7 @@ template <class DS> FT_DEV Scene scene_view(const DS& g) {
     s.nodes = to_const_as(reinterpret_cast<const double*>(g.nodes)); s.bsp_leaves = to_const_as(reinterpret_cast<const uint32_t*>(g.bsp_leaves));
     s.tris = to_const_as(g.tris); s.culls = to_const_as(g.culls); s.tri_orig = to_const_as(g.tri_orig); s.wide = to_const_as(g.wide); s.mesh_wide = to_const_as(g.mesh_wide);
     s.tex_pixels = g.tex_pixels; s.cull_items = g.cull_items; s.coarse_boxes = g.coarse_boxes; s.cull_rows = to_const_as(g.cull_rows); s.item_pc = to_const_as(g.item_pc); s.n_items = g.n_items; s.n_cull_rows = g.n_cull_rows;
-    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap; s.csg_rows = g.csg_rows; s.lane_fold = g.lane_fold; s.n_simd = g.n_simd; s.n_hollow = g.n_hollow;
+    s.n_leaves = g.n_leaves; s.n_lights = g.n_lights; s.csg_cap = g.csg_cap; s.stack_cap = g.stack_cap; s.csg_rows = g.csg_rows; s.lane_fold = g.lane_fold; s.n_simd = g.n_simd;
     return s;
 }
 struct MaterialV { double colour[3]; double roughness, reflectance, shineyness; uint32_t apply_lighting; int32_t texture; uint32_t hue_rot; };
@@ -839,8 +839,7 @@ FT_DEV bool cone_may_reach(float ix, float iy, float iz, float radius, uint32_t 
     return !(beyond > reach) || (rows & B.par_rows) != 0u;
 }
 // Lane k tests top-level ITEM k: bit k of the result is clear only when no ray inside the cone can give a usable hit on it.
-struct SegmentEnds { float cx, cy, cz, rho; };                      // the far ends of a bundle of segments: within rho of c
-FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B, const SegmentEnds* seg = nullptr) {
+FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B) {
     ItemMask M{~0ull, ~0ull, true};
     const float origin_mag = fabsf(B.cx) + fabsf(B.cy) + fabsf(B.cz);
     const int n_pass = S.n_items > 64 ? 2 : 1;
@@ -851,20 +850,6 @@ FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B, const SegmentEnds* 
             const float* I = S.cull_items + 8 * (item + (int)opaque_zero());   // (worked out here: hoisted out of the batch loop, the address was spilled)
             const uint32_t rows = __float_as_uint(I[4]);
             keep = cone_may_reach(I[0], I[1], I[2], I[3], rows, B, origin_mag);
-            // A - B with B a sphere (under any transform: an ellipsoid, convex) cannot be hit between two points that both lie inside B:
-            // along such a segment the line is inside B (no B crossing), and an A crossing met while inside B is discarded by the
-            // subtract table (Csg.fs:27-33: BIntoAB, ABleaveA).  Shadow segments towards a point light all end at the light; their
-            // origins lie within `seg->rho` of seg->c.  Both must be inside B by a margin far above the float arithmetic here.
-            const uint32_t hollow = __float_as_uint(I[7]);
-            if (seg && keep && hollow != 0u && __float_as_uint(I[6]) == 0u && (rows & B.par_rows) == 0u) {
-                const float* Hm = S.cull_items + 8 * hollow;                   // 12 floats: world -> model of B (a unit sphere there), [12]: bound of its 3x3 norm
-                auto inside = [&](float x, float y, float z, float pad) {
-                    const float qx = Hm[0] * x + Hm[1] * y + Hm[2] * z + Hm[3], qy = Hm[4] * x + Hm[5] * y + Hm[6] * z + Hm[7], qz = Hm[8] * x + Hm[9] * y + Hm[10] * z + Hm[11];
-                    const float slack = 1e-5f * (1.0f + fabsf(x) + fabsf(y) + fabsf(z)) * Hm[12];
-                    return sqrtf(qx * qx + qy * qy + qz * qz) + pad * Hm[12] + slack < 0.9999f;
-                };
-                if (inside(B.cx, B.cy, B.cz, B.rho) && inside(seg->cx, seg->cy, seg->cz, seg->rho)) keep = false;
-            }
         }
         const unsigned long long km = __ballot(keep && item < S.n_items);
         if (pass == 0) M.lo = km; else M.hi = km;
@@ -901,15 +886,7 @@ FT_DEV ItemMask bundle_cull_to_light(const Scene& S, const Ray& r, bool live, cd
         cdp Rw = S.cull_rows + 3u * (uint32_t)k;
         if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
     }
-    // the origins, for the items that cannot be hit between two points inside them (items_in_cone): within seg.rho of the first one
-    const float ox = (float)r.ox, oy = (float)r.oy, oz = (float)r.oz;
-    SegmentEnds seg{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox), first)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy), first)),
-                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oz), first)), 0.0f};
-    if (S.n_hollow > 0) {
-        const float dx = ox - seg.cx, dy = oy - seg.cy, dz = oz - seg.cz;
-        seg.rho = sqrtf(wave_max(live ? dx * dx + dy * dy + dz * dz : 0.0f)) * 1.0001f + 1e-5f * (1.0f + fabsf(seg.cx) + fabsf(seg.cy) + fabsf(seg.cz));
-    }
-    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, far * 1.0001f + rho}, S.n_hollow > 0 ? &seg : nullptr);
+    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, far * 1.0001f + rho});
 }
 FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     ItemMask M{~0ull, ~0ull, false};
@@ -994,7 +971,44 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
         M.valid = true;
         return M;
     }
+    // A float image of the same test comes first: it may only say "certainly missed" (every rounding of the float arithmetic is covered
+    // by explicit slack, a ray nearly parallel to one of the item's face directions is never turned away), and the exact test - a
+    // 192-byte record and ~45 FP64 instructions - only runs for the items some lane's float test could not rule out.  An incoherent
+    // wave meets most of a scene's items this way (hollow-sphere: 26 per query, 4 of them needed).
+    const float ox = (float)r.ox, oy = (float)r.oy, oz = (float)r.oz, dx = (float)r.dx, dy = (float)r.dy, dz = (float)r.dz;
+    const float dd = dx * dx + dy * dy + dz * dz;
+    const bool tame = live && dd > 1e-30f && dd < 1e30f && fabsf(ox) < 1e15f && fabsf(oy) < 1e15f && fabsf(oz) < 1e15f;   // else: no float verdicts for this lane
+    uint32_t par_lane = 0;                                         // face directions this lane's ray is nearly parallel to (Plane.fs:13-16)
+    const bool rows_known = S.n_cull_rows >= 0;                    // (more than 32 distinct directions in the scene: the table does not exist)
+    for (int k = 0; k < S.n_cull_rows; ++k) {
+        cdp Rw = S.cull_rows + 3u * (uint32_t)k;
+        if (fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.000001 * kEps) par_lane |= 1u << k;
+    }
+    // The float records sit in the lanes (lane j: items j and 64 + j, one vector load each before the loop) and are handed round by
+    // v_readlane: fetched one by one through scalar loads, every item of the loop began with a memory round trip of its own - the
+    // fixed ~17 us a batch of incoherent rays cost whatever it held was mostly this loop, twice (closest, then shadow).
+    struct ItemRec { float x, y, z, r, rows; };
+    auto load_rec = [&](int item) {
+        const float* I = S.cull_items + 8 * ((item < n ? item : 0) + (int)opaque_zero());
+        return ItemRec{I[0], I[1], I[2], I[3], I[4]};
+    };
+    const ItemRec lo = load_rec((int)lane_id());
+    ItemRec hi{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (n > 64) hi = load_rec(64 + (int)lane_id());
+    auto lane_of = [](float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); };
     for (int k = 0; k < n; ++k) {
+        const int src = k & 63;
+        const bool first = k < 64;                                  // wave-uniform
+        const float I[5] = {lane_of(first ? lo.x : hi.x, src), lane_of(first ? lo.y : hi.y, src), lane_of(first ? lo.z : hi.z, src),
+                            lane_of(first ? lo.r : hi.r, src), lane_of(first ? lo.rows : hi.rows, src)};
+        const float cx = ox - I[0], cy = oy - I[1], cz = oz - I[2], rad = I[3];
+        const uint32_t rows = __float_as_uint(I[4]);
+        const float b = cx * dx + cy * dy + cz * dz, cc = cx * cx + cy * cy + cz * cz, r2 = rad * rad * 1.001f;
+        const float slack = 1e-4f * (cc * dd) + 1e-30f;
+        const bool line_misses = (cc * dd - b * b) > r2 * dd + slack;              // the line passes the (inflated) bounding sphere by a margin
+        const bool leaves = cc > r2 + 1e-4f * cc && b > 0.0f && b * b > 1e-6f * (cc * dd);   // outside it and moving away: every hit has t < 0
+        const bool certainly_missed = tame && rows_known && (line_misses || leaves) && (rows & par_lane) == 0u && rad < 1e30f;
+        if (!__any(live && !certainly_missed)) continue;
         const bool need = live && !item_missed(S, (uint32_t)k, r);
         if (__any(need)) { if (k < 64) M.lo |= 1ull << k; else M.hi |= 1ull << (k - 64); }
     }
@@ -1003,10 +1017,22 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
 }
 
 #ifdef FT_ITEM_COUNTS
+// Diagnostic build only: shader-clock cycles waves spend in sections of the tracing kernels (s_memtime; summed over waves).
+// Every wave adds to 48 words of its own (no-return atomics on addresses nobody shares: shared words made the build eight times slower).
+__device__ unsigned long long g_clk[8192 * 48];
+#define FT_CLK_SLOT() (((blockIdx.x * (kBlock / 64) + threadIdx.x / 64) & 8191u) * 48u)
+#define FT_CLK_NOW() __builtin_amdgcn_s_memtime()
+#define FT_CLK_ADD(k, t0) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) atomicAdd(&g_clk[FT_CLK_SLOT() + 16 + (k)], t1_ - (t0)); } while (0)
+#define FT_CLK_INC(k) do { if (lane_id() == 0) atomicAdd(&g_clk[FT_CLK_SLOT() + 16 + (k)], 1ull); } while (0)
+#else
+#define FT_CLK_NOW() 0ull
+#define FT_CLK_ADD(k, t0) do { (void)(t0); } while (0)
+#define FT_CLK_INC(k) do { } while (0)
+#endif
+#ifdef FT_ITEM_COUNTS
 // Diagnostic build only (tools/item_counts.py): how many top-level items a wave's query evaluates.  [4 * kind + k], kind = ANY * 2 + incoherent:
 // k = 0 queries, 1 items evaluated, 2 live lanes, 3 items the mask offered (before each item's own OP_CULL).
-__device__ unsigned long long g_item_counts[16];
-#define FT_COUNT(k, v) do { if (lane_id() == 0) atomicAdd(&g_item_counts[4 * ((ANY ? 2 : 0) + (coherent ? 0 : 1)) + (k)], (unsigned long long)(v)); } while (0)
+#define FT_COUNT(k, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane_id() == 0) atomicAdd(&g_clk[FT_CLK_SLOT() + 4 * ((ANY ? 2 : 0) + (coherent ? 0 : 1)) + (k)], v_); } while (0)
 #else
 #define FT_COUNT(k, v) do { } while (0)
 #endif
@@ -1023,9 +1049,12 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
     // go to the earlier one); everything else walks the whole program, every item behind its own OP_CULL.
     ItemMask IM{~0ull, ~0ull, false};
     const bool live = ANY ? (q.active && !q.blocked) : q.active;
+    const unsigned long long clk0 = FT_CLK_NOW();
     if (coherent) IM = (ANY && to_light && S.n_items >= 3 && S.n_cull_rows >= 0) ? bundle_cull_to_light(S, r, live, to_light, q.max_dist) : bundle_cull(S, r, live);
     const bool exact_mask = !IM.valid;                             // the bundle bounded nothing (or was not tried): per-ray tests up front
     if (exact_mask) IM = exact_cull(S, r, live);
+    FT_CLK_ADD(4 * ((ANY ? 2 : 0) + (coherent ? 0 : 1)) + 0, clk0);
+    const unsigned long long clk1 = FT_CLK_NOW();
     FT_COUNT(0, 1); FT_COUNT(2, __popcll(__ballot(live))); FT_COUNT(3, IM.valid ? __popcll(IM.lo) + __popcll(IM.hi) : S.n_items);
     uint32_t item_end = 0xFFFFFFFFu;
     for (uint32_t pc = 0;; ++pc) {
@@ -1037,7 +1066,10 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
             else break;
             const uint32_t at = S.item_pc[k];
             pc = at & 0x7FFFFFFFu;
-            if (exact_mask && IM.valid && (at >> 31)) pc += 2;     // its OP_CULL was already evaluated for every lane
+            // its OP_CULL was already evaluated for every lane (exact mask) - or, for the closest hits of a bundle, turns almost nothing
+            // away that the cone test let through (measured: 1.23 items offered, 1.22 evaluated per query on hollow-sphere; 1.48 / 1.46 on
+            // night-house) and costs ~45 FP64 instructions per item; shadow bundles keep it (it rejects 12 - 40 % of what they are offered)
+            if (IM.valid && (at >> 31) && (exact_mask || !ANY)) pc += 2;
             item_end = IM.valid ? (S.item_pc[k + 1] & 0x7FFFFFFFu) : 0xFFFFFFFFu;
         }
         const uint32_t ins = S.program[pc];                        // wave-uniform: scalar load
@@ -1160,6 +1192,7 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
         }
         if (ANY) { if (__all(q.blocked || !q.active)) break; }    // every lane already in shadow
     }
+    FT_CLK_ADD(4 * ((ANY ? 2 : 0) + (coherent ? 0 : 1)) + 1, clk1);
     overflow = L.overflow;
 }
 
@@ -1713,6 +1746,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
     for (uint32_t bi = cursor.grab(), bi_next = cursor.grab(); bi < n_batches; bi = bi_next, bi_next = cursor.grab()) {
         const uint32_t i = bi * B + lane_id();
         bool alive = i < n && lane_id() < B;
+        const unsigned long long clk_batch = FT_CLK_NOW();
         Ray r{0, 0, 0, 0, 0, 0};
         double w = 0.0; uint32_t slot = 0;
         if (alive) {
@@ -1726,7 +1760,9 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
             Query<false> q;
             q.active = alive; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
             bool overflow;
+            const unsigned long long clk_a = FT_CLK_NOW();
             trace<false, MESH>(S, ro, q, lds, overflow, false);
+            FT_CLK_ADD(16, clk_a);
             n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && alive));
             const bool hit = alive && q.id0 != ID_MISS;
             const unsigned long long hit_mask = __ballot(hit);
@@ -1741,7 +1777,11 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
                 if (SOFT) sample = sample_id(&fresh(K)->gen, px, slot);
             }
             unsigned long long vis_lo, vis_hi;
+            FT_CLK_ADD(17, clk_a);
+            const unsigned long long clk_b = FT_CLK_NOW();
             light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, depth, false, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
+            FT_CLK_ADD(18, clk_b);
+            const unsigned long long clk_c = FT_CLK_NOW();
             MaterialV mat = material_at(S, sf.material);
             if (FANCY) { if (hit && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
             double cr, cg, cb;
@@ -1772,8 +1812,10 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
                     next.w[o] = w * (mat.reflectance * lights_f);
                     next.slot[o] = slot;
                 }
+                FT_CLK_ADD(19, clk_c);
                 break;
             }
+            FT_CLK_ADD(19, clk_c);
             if (cnt == 0u) break;
             if (lane_id() == 0) atomicAdd(&K2->fc->cc.n_rays[depth + 1], cnt);   // counted all the same: the host sizes the next frame's launches from these
             if (spawn) {                                            // followed in registers: same ray, same weight as the queued one would carry
@@ -1782,6 +1824,7 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
             }
             alive = spawn;
         }
+        FT_CLK_ADD(20, clk_batch); FT_CLK_INC(21);
     }
     RenderCounters* mine = my_stats(fresh(K)->fc);
     wave_add(&mine->rays_shadow, n_shadow_wave);
@@ -2255,9 +2298,11 @@ void launch_resolve(const Launch& L, const ResolveArgs& a) {
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, cus * resident)), dim3(kBlock), 0, L.stream, a);
 }
 #ifdef FT_ITEM_COUNTS
-extern "C" int ft_debug_item_counts(unsigned long long out[16], int reset) {
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_item_counts), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) { const unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_item_counts), z, sizeof z) != hipSuccess) return -1; }
+extern "C" int ft_debug_item_counts(unsigned long long out[48], int reset) {      // [0..15] item counters, [16..47] section clocks, summed over the waves' slots
+    static unsigned long long host[8192 * 48];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk), sizeof host) != hipSuccess) return -1;
+    for (int k = 0; k < 48; ++k) { out[k] = 0; for (int w = 0; w < 8192; ++w) out[k] += host[w * 48 + k]; }
+    if (reset) { static const unsigned long long z[8192 * 48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof z) != hipSuccess) return -1; }
     return 0;
 }
 #endif

@@ -102,8 +102,6 @@ struct Flattener {
     int cur_list = 0, max_list = 0;                  // static bound on the per-lane hit-list length
     std::vector<bool> leaf_bounds;                   // per leaf: its box is part of its item's bounds (WalkCtx::bounds)
     std::map<const GraphNode*, size_t> image_base;   // image texture node -> offset of its pixels in out.tex_pixels
-    int64_t hollow_leaf = -1;                        // the item being closed is A - B with B this bare sphere leaf (ft_kernels.hip, items_in_cone)
-    std::vector<std::pair<size_t, std::array<float, 16>>> hollows;   // (item, B's record)
 
     Flattener(const SceneGraph& g_, FlatScene& o, std::string& e) : g(g_), out(o), err(e) {}
 
@@ -284,14 +282,6 @@ struct Flattener {
                 const uint32_t mesh = out.leaves[m.leaf_at].mesh, w[3] = {out.mesh_coarse[2 * mesh], out.mesh_coarse[2 * mesh + 1], (uint32_t)m.leaf_at};
                 std::memcpy(&rec[5], w, sizeof w);
             }
-            if (hollow_leaf >= 0) {                                 // A - sphere: B's world -> model matrix, rounded to float, and a bound of its 3x3 norm
-                const ftd::Leaf& B = out.leaves[(size_t)hollow_leaf];
-                std::array<float, 16> h{};
-                double frob = 0.0;
-                for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) { h[4 * r + k] = (float)B.w2m[4 * r + k]; if (k < 3) frob += B.w2m[4 * r + k] * B.w2m[4 * r + k]; }
-                h[12] = (float)(std::sqrt(frob) * 1.001);
-                if (std::isfinite(h[12])) hollows.push_back({out.cull_items.size() / 8, h});
-            }
             out.cull_items.insert(out.cull_items.end(), rec, rec + 8);
             out.item_pc.push_back((uint32_t)m.prog_at | (exact ? 0x80000000u : 0u));   // top bit: the item starts with its OP_CULL pair
         }
@@ -408,8 +398,6 @@ struct Flattener {
                 if (a_gates) out.program.push_back(ftd::make_op(ftd::OP_SKIP_IF_EMPTY, 0));
                 out.program.push_back(ftd::make_op(ftd::OP_MARK, 0));
                 walk(n.children[1], cb, true);
-                hollow_leaf = (!in_csg && n.op == FT_CSG_SUBTRACT && bare_primitive(n.children[1]) && status == FT_OK && !out.leaves.empty() &&
-                               out.leaves.back().kind == ftd::LK_SPHERE) ? (int64_t)out.leaves.size() - 1 : -1;
                 out.program.push_back(ftd::make_op(ftd::OP_CSG, (uint32_t)n.op));
                 if (a_gates) out.program[skip_at] = ftd::make_op(ftd::OP_SKIP_IF_EMPTY, (uint32_t)(out.program.size() - skip_at - 1));
                 --csg_depth;
@@ -422,7 +410,6 @@ struct Flattener {
                     out.program.erase(out.program.begin() + (long)pair_at, out.program.begin() + (long)pair_at + 3);
                 }
                 end_item(im);
-                hollow_leaf = -1;
                 break;
             }
         }
@@ -440,15 +427,6 @@ int32_t SceneGraph::flatten(FlatScene& out, std::string& err) const {
     if (f.status != FT_OK) return f.status;
     out.item_pc.push_back((uint32_t)out.program.size());
     out.program.push_back(ftd::make_op(ftd::OP_END, 0));
-    {   // the B records of the A - sphere items, behind the item records; [7] of such an item: where its record starts, in units of 8 floats
-        const size_t n_items = out.cull_items.size() / 8;
-        for (size_t k = 0; k < f.hollows.size(); ++k) {
-            const uint32_t unit = (uint32_t)(n_items + 2 * k);
-            std::memcpy(&out.cull_items[8 * f.hollows[k].first + 7], &unit, 4);
-        }
-        for (auto& h : f.hollows) out.cull_items.insert(out.cull_items.end(), h.second.begin(), h.second.end());
-        out.n_hollow = (int32_t)f.hollows.size();
-    }
     out.lights = lights;
     out.csg_capacity = f.max_list;
     if (f.max_csg_depth > 8) { err = "CSG nesting deeper than 8 levels is not supported on the device path"; return FT_ERR_UNSUPPORTED; }

@@ -48,7 +48,6 @@ struct FlatScene {
     std::vector<uint32_t> item_pc;    // program counter of every top-level item, in order, + one sentinel (the OP_END word)
     std::vector<float> cull_items;    // 8 floats per top-level item: centre, radius (rounded up; +inf = unbounded), row mask (bits), pad - the wave-level pre-test
     std::vector<double> cull_rows;    // 3 per distinct parallel-sensitive direction of the whole scene (<= 32, else the pre-test is off)
-    int32_t n_hollow = 0;             // items of the form A - sphere: their B records (16 floats each) follow the item records in cull_items
     bool unbounded = false;           // some top-level item has no bounds (a plane): every pixel block can see something, k_classify has nothing to do
     bool cull_bundle = true;          // false: more than 32 distinct directions
     std::vector<double> mesh_bounds;  // 6 per mesh: model-space AABB of the source triangles (lo > hi when empty)

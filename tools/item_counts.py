@@ -6,7 +6,7 @@ import functracer_amd as ft
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 lib = ft.hip_lib()
 ctx = ft.Context(0)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 48)()
 for name, spp in (("hollow-sphere", 16), ("hollow-sphere", 1), ("night-house-det", 16), ("sample-det", 16), ("bunny", 16)):
     p = ft.parse_scene_file(os.path.join(R, "scenes", name + ".scene")); p.lower(ctx)
     jit = ft.jitter_pattern(spp)
@@ -19,4 +19,9 @@ for name, spp in (("hollow-sphere", 16), ("hollow-sphere", 1), ("night-house-det
     for k, label in enumerate(("closest coherent", "closest incoherent", "any coherent", "any incoherent")):
         q, items, lanes, offered = v[4 * k:4 * k + 4]
         if q:
-            print(f"   {label:20s} wave-queries {q:9d}  items evaluated / query {items / q:6.2f}  offered by the mask {offered / q:6.2f}  live lanes {lanes / q:5.1f}")
+            cull, loop = v[16 + 4 * k], v[16 + 4 * k + 1]
+            print(f"   {label:20s} wave-queries {q:9d}  items evaluated / query {items / q:6.2f}  offered by the mask {offered / q:6.2f}  cycles / query: cull {cull / q:8.0f} item loop {loop / q:8.0f}")
+    clk = v[16:]
+    if clk[21]:
+        nb = clk[21]
+        print(f"   k_bounce per batch ({nb} batches): total {clk[20] / nb:9.0f} cycles = closest trace {clk[16] / nb:8.0f} + surface {(clk[17] - clk[16]) / nb:8.0f} + shadow queries {clk[18] / nb:8.0f} + shading / store / spawn {clk[19] / nb:8.0f}")
