@@ -17,10 +17,7 @@
 #include "ft_device.h"
 #include "ft_scene.h"
 
-namespace ftk {
-int occupancy_blocks_primary(size_t lds_bytes, int* variant);
-int occupancy_blocks_bounce(size_t lds_bytes, int variant);
-}
+
 
 struct DeviceBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -61,11 +58,34 @@ struct ft_context {
     bool level_hint = true;         // launch only as many k_bounce levels as the previous frame of the same signature had (+ 1); 0: always max_depth
 
     // scene in HBM
-    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_block_pos, d_pos_block, d_wave_counts, d_wide, d_mesh_wide, d_coarse;
+    DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_wave_counts, d_wide, d_mesh_wide, d_coarse;
+    // What k_classify writes and the frame's later kernels read exists once per frame slot, so that a queued frame's classification can
+    // run (on `side`, behind an event) while the frame before it is still tracing: block_pos / pos_block and the frame's counters.
+    DeviceBuf d_block_pos[2], d_pos_block[2], d_fc[2];
+    hipStream_t side = nullptr;     // the second stream: k_classify of frame N + 1 beside k_primary's tail / k_resolve of frame N (ft_render_enqueue)
+    bool classify_ahead = true;     // option "classify_ahead": 0 keeps every kernel on the one stream
+    bool classify_after_trace = false;   // option "classify_after_trace": the classification run ahead waits for the previous frame's tracing kernels
+    // Kernel variants and resident workgroups per CU for the committed scene (they only change at commit): bit 0 FANCY, 1 SOFT, 2 MESH; the
+    // primary's variant may carry bit 3 (the five-workgroup lean build).
+    int variant = 0, variant_primary = 0, blocks_primary = 1, blocks_bounce = 1, blocks_resolve = 2;
+    int resolve_blocks_cap = 0;     // option "resolve_blocks": k_resolve workgroups per CU (0: every resident one)
+    hipEvent_t classified = nullptr;  // behind the latest k_classify on either stream: the next one waits for it (they share the ticket words of d_wave_counts)
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
-    DeviceBuf d_rays[2], d_acc, d_out, d_out8, d_pixels, d_jitter, d_fc, d_dbg_in, d_dbg_out;
-    bool fc_clean = false;          // d_fc is all zero: the previous frame's last kernel cleared it behind its report (no fill needed)
+    DeviceBuf d_rays[2], d_acc[2], d_out, d_out8, d_pixels, d_jitter, d_dbg_in, d_dbg_out;
+    // The sample colours exist twice: a queued frame's k_resolve runs on a stream of its own (`tail`), behind an event, while the next
+    // chunk's / frame's k_primary already fills the other copy - the small kernel hides in the big one's ramp instead of standing between
+    // two of them.  acc_free[i]: behind the last k_resolve that read copy i (the next k_primary into that copy waits for it).
+    int acc_turn = 0;
+    hipStream_t tail = nullptr;
+    hipEvent_t acc_free[2] = {nullptr, nullptr};
+    bool acc_busy[2] = {false, false};
+    bool resolve_aside = true;      // option "resolve_aside": 0 keeps k_resolve on the main stream
+    bool fc_clean[2] = {false, false};   // d_fc[slot] is all zero: the slot's previous frame cleared it behind its report (no fill needed)
+    // Colour.Zero in the blocks k_classify finished: what the last frame written into d_out / d_out8 classified (scene, camera, size, pixel
+    // list, jitter extent).  A frame of the same signature finds those pixels zero already and does not write them again.
+    uint64_t zero_signature[2] = {0, 0};
+    bool zero_fill_skip = true;     // option "zero_fill_skip"
     uint32_t classify_epoch = 0;    // tags the entries k_classify's waves publish in d_wave_counts (cleared only when it wraps or the buffer grows)
     int64_t ray_capacity = 0, acc_capacity = 0;
     // Per-frame host state.  Two slots, so that one frame can be queued while the previous one still runs (ft_render_enqueue).
@@ -74,6 +94,7 @@ struct ft_context {
         struct Span { hipEvent_t a, b; int kind; };
         std::vector<Span> spans;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
+        hipEvent_t traced = nullptr;            // behind the frame's last tracing kernel, in front of its k_resolve: where the NEXT frame's k_classify may start
         ftk::FrameReport* h_report = nullptr;   // pinned: the frame's statistic stripes, k_classify's error word and the last chunk's rays per bounce,
         ftk::FrameReport* d_report = nullptr;   // written by the frame's last kernel through this device-side address of the same memory
         int levels_launched = 0, last_bounce = 0;
@@ -150,7 +171,7 @@ ftk::RayBuf ray_view(const DeviceBuf& b, int64_t cap) {
 // Per-sample accumulators for every frame; the ray wavefront buffers only for scenes with reflective materials (bounce >= 1).
 int32_t ensure_frame_buffers(ft_context* c, int64_t cap, bool reflective) {
     int32_t rc;
-    if (cap > c->acc_capacity) { if ((rc = ensure(c, c->d_acc, (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
+    if (cap > c->acc_capacity) { for (int k = 0; k < 2; ++k) if ((rc = ensure(c, c->d_acc[k], (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
     if (!reflective || cap <= c->ray_capacity) return FT_OK;
     for (int i = 0; i < 2; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;
     c->ray_capacity = cap;
@@ -219,6 +240,12 @@ static int32_t create_single(int32_t device_id, int count, ft_context** out) {
     hipDeviceProp_t prop;
     if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FT_ERR_HIP; }
+    int pr_low = 0, pr_high = 0;                                   // the side stream's few workgroups go first whenever slots come free
+    if (hipDeviceGetStreamPriorityRange(&pr_low, &pr_high) != hipSuccess) pr_high = 0;
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr_high) != hipSuccess || hipStreamCreateWithPriority(&c->tail, hipStreamNonBlocking, pr_high) != hipSuccess) {
+        if (c->side) (void)hipStreamDestroy(c->side);
+        (void)hipStreamDestroy(c->stream); delete c; return FT_ERR_HIP;
+    }
     c->n_cu = prop.multiProcessorCount;
     *out = c;
     return FT_OK;
@@ -260,11 +287,17 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos, &c->d_pos_block, &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
-                             &c->d_rays[0], &c->d_rays[1], &c->d_acc, &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc,
+        if (c->side) (void)hipStreamSynchronize(c->side);
+        if (c->tail) (void)hipStreamSynchronize(c->tail);
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos[0], &c->d_block_pos[1], &c->d_pos_block[0], &c->d_pos_block[1], &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
+                             &c->d_rays[0], &c->d_rays[1], &c->d_acc[0], &c->d_acc[1], &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc[0], &c->d_fc[1],
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
-        for (auto& f : c->slots) { if (f.h_report) { (void)hipHostFree(f.h_report); f.h_report = nullptr; f.d_report = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
+        for (auto& f : c->slots) { if (f.traced) { (void)hipEventDestroy(f.traced); f.traced = nullptr; } if (f.h_report) { (void)hipHostFree(f.h_report); f.h_report = nullptr; f.d_report = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
+        if (c->classified) (void)hipEventDestroy(c->classified);
+        for (hipEvent_t& e : c->acc_free) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (c->side) (void)hipStreamDestroy(c->side);
+        if (c->tail) (void)hipStreamDestroy(c->tail);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -284,6 +317,11 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
         c->wave_samples_log2 = l; for (ft_context* p : c->peers) p->wave_samples_log2 = l; return FT_OK;
     }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
+    if (!std::strcmp(key, "resolve_aside")) { c->resolve_aside = value != 0; for (ft_context* p : c->peers) p->resolve_aside = value != 0; return FT_OK; }
+    if (!std::strcmp(key, "resolve_blocks")) { if (value < 0 || value > 8) return FT_ERR_INVALID; c->resolve_blocks_cap = (int)value; for (ft_context* p : c->peers) p->resolve_blocks_cap = (int)value; return FT_OK; }
+    if (!std::strcmp(key, "classify_after_trace")) { c->classify_after_trace = value != 0; for (ft_context* p : c->peers) p->classify_after_trace = value != 0; return FT_OK; }
+    if (!std::strcmp(key, "classify_ahead")) { c->classify_ahead = value != 0; for (ft_context* p : c->peers) p->classify_ahead = value != 0; return FT_OK; }
+    if (!std::strcmp(key, "zero_fill_skip")) { c->zero_fill_skip = value != 0; c->zero_signature[0] = c->zero_signature[1] = 0; for (ft_context* p : c->peers) { p->zero_fill_skip = value != 0; p->zero_signature[0] = p->zero_signature[1] = 0; } return FT_OK; }
     if (!std::strcmp(key, "classify_pixels")) { c->classify_pixels = value != 0; for (ft_context* p : c->peers) p->classify_pixels = value != 0; return FT_OK; }
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
     if (!std::strcmp(key, "follow_below")) { if (value < -1) return FT_ERR_INVALID; c->follow_below = value; c->staged_hint = -1; for (ft_context* p : c->peers) { p->follow_below = value; p->staged_hint = -1; } return FT_OK; }
@@ -453,8 +491,8 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_mesh_wide, f.mesh_wide)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_coarse, f.coarse_boxes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
-    if ((rc = ensure(c, c->d_fc, sizeof(ftk::FrameCounters))) != FT_OK) return rc;
-    c->fc_clean = false;
+    for (int k = 0; k < 2; ++k) { if ((rc = ensure(c, c->d_fc[k], sizeof(ftk::FrameCounters))) != FT_OK) return rc; c->fc_clean[k] = false; }
+    c->zero_signature[0] = c->zero_signature[1] = 0;
     FT_HIP(c, hipStreamSynchronize(c->stream));
     {   // the BVHs the flattener left to the device (ft_bvh.hip), straight into the ranges reserved in the arrays just uploaded
         const auto t0 = std::chrono::steady_clock::now();
@@ -492,6 +530,15 @@ static int32_t upload_scene(ft_context* c) {
     S.lane_fold = lane_fold_for(f); S.csg_rows = (f.csg_capacity + S.lane_fold - 1) / S.lane_fold;
     S.shadow_rays_per_hit = 0;
     for (auto& l : f.lights) S.shadow_rays_per_hit += (l.kind == ftd::LT_SOFT) ? l.samples : 1;   // Shading.fs:24-42
+    c->variant = 0;
+    for (auto& m : f.materials) if (needs_fancy(m)) c->variant |= 1;                               // FANCY
+    for (auto& l : f.lights) if (l.kind == ftd::LT_SOFT) c->variant |= 2;                          // SOFT
+    if (!f.meshes.empty()) c->variant |= 4;                                                        // MESH
+    const size_t lds = lds_bytes_for(c->flat);
+    c->variant_primary = c->variant;
+    c->blocks_primary = ftk::occupancy_blocks_primary(lds, &c->variant_primary);
+    c->blocks_bounce = ftk::occupancy_blocks_bounce(lds, c->variant);
+    c->blocks_resolve = ftk::occupancy_blocks_resolve();
     c->committed = true;
     ++c->commit_serial; c->staged_hint = -1;
     return FT_OK;
@@ -505,7 +552,8 @@ static int32_t fetch_single(ft_context* c, void* out, int format) {
     if (c->last_n_pix <= 0) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
     if (format != c->last_format) { c->err = format == 1 ? "the last frame was rendered as FP64 RGB (ft_render): no RGBA8 frame to fetch" : "the last frame was rendered as RGBA8 (ft_render_rgba8): no FP64 frame to fetch"; return FT_ERR_STATE; }
     FT_HIP(c, hipSetDevice(c->device));
-    FT_HIP(c, hipStreamSynchronize(c->stream));                     // frames queued with ft_render_enqueue may still be running (the stream is non-blocking)
+    FT_HIP(c, hipStreamSynchronize(c->stream));                     // frames queued with ft_render_enqueue may still be running (the streams are non-blocking)
+    FT_HIP(c, hipStreamSynchronize(c->tail));                       // ... their k_resolve on its own stream
     const size_t px = format == 1 ? 4 : 24, pitch = (size_t)c->last_res_h * px;
     const char* src = static_cast<const char*>(format == 1 ? c->d_out8.p : c->d_out.p);
     char* dst = static_cast<char*>(out);
@@ -770,8 +818,12 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     const int last_bounce = c->flat.any_reflective ? max_depth : 0;   // no reflective material ⇒ no reflection rays are ever spawned
     if ((rc = ensure_frame_buffers(c, cap, last_bounce > 0)) != FT_OK) return rc;
     const size_t frame_pixels = (size_t)res_h * (size_t)res_v;
-    if (q.format == 1) { if ((rc = ensure(c, c->d_out8, frame_pixels * 4)) != FT_OK) return rc; }
-    else if ((rc = ensure(c, c->d_out, frame_pixels * 24)) != FT_OK) return rc;
+    {
+        DeviceBuf& ob = q.format == 1 ? c->d_out8 : c->d_out;
+        const void* before = ob.p;
+        if ((rc = ensure(c, ob, frame_pixels * (q.format == 1 ? 4 : 24))) != FT_OK) return rc;
+        if (ob.p != before) c->zero_signature[q.format] = 0;       // a new allocation holds nothing yet
+    }
     if (corner) {
         if ((rc = upload(c, c->d_pixels, corner_ids)) != FT_OK) return rc;
         if ((rc = upload(c, c->d_out_index, pixels)) != FT_OK) return rc;
@@ -779,33 +831,42 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     std::vector<double> jit;
     if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
     else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
+    bool jitter_uploaded = false;
     if (jit != c->jitter_on_device) {                              // frames usually reuse the pattern: skip the staged host-to-device copy
         c->jitter_on_device = jit;                                 // (the copy source outlives this call)
         if ((rc = upload(c, c->d_jitter, c->jitter_on_device)) != FT_OK) return rc;
+        jitter_uploaded = true;
     }
+    // A blocking call retires whatever is in flight first; a deferred one only the frame whose slot (host state, counters, classification
+    // buffers) it is about to reuse.
+    if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < kStages; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
+    const int turn = c->slot_turn;
+    ft_context::FrameSlot& F = c->slots[turn];
+    if (F.pending) { int32_t prc = retire_frame(c, F, nullptr); if (prc != FT_OK) return prc; }
+    if (defer && !c->accum_open) { for (int k = 0; k < kStages; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = true; }
+    bool uploads_queued = !same_list || corner || jitter_uploaded; // something this frame's k_classify reads is still on its way on the main stream
     ftk::ClassifyOut cls{};
     if (classify) {
         const size_t n_blocks = (size_t)n_pix_total / 64, n_waves = (n_blocks + 255) / 256;   // one word per k_classify workgroup
-        if ((rc = ensure(c, c->d_block_pos, n_blocks * 4)) != FT_OK) return rc;
-        if ((rc = ensure(c, c->d_pos_block, n_blocks * 4)) != FT_OK) return rc;
+        if ((rc = ensure(c, c->d_block_pos[turn], n_blocks * 4)) != FT_OK) return rc;
+        if ((rc = ensure(c, c->d_pos_block[turn], n_blocks * 4)) != FT_OK) return rc;
         if (c->d_wave_counts.bytes < n_waves * 4 || c->classify_epoch >= 0x3FFFFEu) {   // entries are tagged with the frame's epoch and never cleared in between
             if ((rc = ensure(c, c->d_wave_counts, std::max<size_t>(n_waves * 4, 4096) + 4096 * 4 + 2048 * 64)) != FT_OK) return rc;   // (+ room for the diagnostic build's stamps)
+            FT_HIP(c, hipStreamSynchronize(c->side));              // (a classification of the other slot may still be publishing into the old words)
             FT_HIP(c, hipMemsetAsync(c->d_wave_counts.p, 0, c->d_wave_counts.bytes, c->stream));
             c->classify_epoch = 0;
+            uploads_queued = true;
         }
-        cls = ftk::ClassifyOut{c->d_block_pos.as<int32_t>(), c->d_pos_block.as<uint32_t>(), c->d_wave_counts.as<uint32_t>()};
+        cls = ftk::ClassifyOut{c->d_block_pos[turn].as<int32_t>(), c->d_pos_block[turn].as<uint32_t>(), c->d_wave_counts.as<uint32_t>()};
     }
-    auto* fc = c->d_fc.as<ftk::FrameCounters>();
-    // chunk counters, statistic stripes, list length, tickets: cleared by the previous frame's last kernel, or by a fill when there was none
-    if (!c->fc_clean) FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream));
-    c->fc_clean = false;                                           // until this frame's own hand-over is queued
+    auto* fc = c->d_fc[turn].as<ftk::FrameCounters>();
+    // chunk counters, statistic stripes, list length, tickets: cleared by the slot's previous frame's last kernel, or by a fill when there was none
+    if (!c->fc_clean[turn]) { FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream)); uploads_queued = true; }
+    c->fc_clean[turn] = false;                                     // until this frame's own hand-over is queued
 
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
     const size_t lds = lds_bytes_for(c->flat);
-    int variant = 0;
-    for (auto& m : c->flat.materials) if (needs_fancy(m)) variant |= 1;                         // FANCY
-    for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;                      // SOFT
-    if (!c->flat.meshes.empty()) variant |= 4;                                                     // MESH
+    const int variant = c->variant;
     // Samples per bounce-0 wavefront (slot_at, ft_kernels.hip): 2^group_log2 samples of 64 / 2^group_log2 pixels when the sample count
     // has that power of two in it and the list is made of whole 8x8 blocks.  Narrow bundles pay most where a wave walks a BVH
     // (measured at 1080p x 16, 1 -> 16 samples per wave: bunny through BSP leaves 1.46 -> 1.29 ms, night-house 4.63 -> 4.45).
@@ -815,18 +876,13 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         while (group_log2 < cap && !((spp >> group_log2) & 1)) ++group_log2;
         if (corner || !c->pixels_tiled) group_log2 = 0;
     }
-    int variant_p = variant;
-    const int blocks_p = ftk::occupancy_blocks_primary(lds, &variant_p);
-    ftk::Launch Lp{c->stream, c->n_cu * blocks_p, lds, variant_p};
-    ftk::Launch Lb{c->stream, c->n_cu * ftk::occupancy_blocks_bounce(lds, variant), lds, variant};
+    ftk::Launch Lp{c->stream, c->n_cu * c->blocks_primary, lds, c->variant_primary};
+    ftk::Launch Lb{c->stream, c->n_cu * c->blocks_bounce, lds, variant};
     ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
+    const int resolve_per_cu = c->resolve_blocks_cap > 0 ? std::min(c->resolve_blocks_cap, c->blocks_resolve) : c->blocks_resolve;
+    ftk::Launch Lr{c->stream, c->n_cu * resolve_per_cu, 0, 0};
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
 
-    // A blocking call retires whatever is in flight first; a deferred one only the frame whose slot it is about to reuse.
-    if (!defer) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; for (int k = 0; k < kStages; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = false; }
-    ft_context::FrameSlot& F = c->slots[c->slot_turn];
-    if (F.pending) { int32_t prc = retire_frame(c, F, nullptr); if (prc != FT_OK) return prc; }
-    if (defer && !c->accum_open) { for (int k = 0; k < kStages; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; } c->accum_open = true; }
     F.events_used = 0; F.spans.clear();
     auto& spans = F.spans;
     using Span = ft_context::FrameSlot::Span;
@@ -850,6 +906,16 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     uint64_t signature = c->commit_serial * 0x9E3779B97F4A7C15ull;
     for (uint64_t v : {(uint64_t)res_h, (uint64_t)res_v, (uint64_t)spp, (uint64_t)max_depth, (uint64_t)n_pix_total, (uint64_t)c->chunk_samples, (uint64_t)(corner ? 1 : 0)})
         signature = (signature ^ v) * 0x100000001B3ull;
+    // What decides which blocks k_classify finishes: the scene, the camera, the frame's size and pixel list, the jitter pattern's extent.
+    uint64_t zsig = signature;
+    {
+        auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t k = 0; k < n; ++k) zsig = (zsig ^ b[k]) * 0x100000001B3ull; };
+        mix(&dcam, sizeof dcam); mix(&jitter_extent, sizeof jitter_extent);
+        if (!rects.empty()) mix(rects.data(), rects.size() * sizeof(ft_rect));
+        zsig |= 1ull;                                              // never 0: 0 means "nothing known about the buffer"
+    }
+    const bool zeros_in_place = classify && c->zero_fill_skip && c->zero_signature[q.format] == zsig;
+    c->zero_signature[q.format] = classify ? zsig : 0;
     int n_chunks = 0, n_launches = 0, levels_launched = 0;
     // The whole frame is classified once; the chunks then take consecutive windows of the frame's ACTIVE pixel list, so a sparse
     // frame is one chunk of real work and launches that find their window empty return at once.
@@ -857,7 +923,30 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         const ftk::Primary all{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), 0u, (uint32_t)n_pix_total, spp, (uint32_t)res_h,
                                (unsigned long long)seed, 1.0 / (double)n_pix_total, 1.0 / (double)res_h, nullptr, nullptr};
         const uint32_t epoch = ++c->classify_epoch;
-        timed(kStageOther, [&] { ftk::launch_classify(Lg, c->dev_scene, all, cls, jitter_extent, epoch, fc); });
+        // A queued frame's classification reads nothing the frames before it write (its slot's buffers were free once the slot's previous
+        // frame was retired above): it goes to the side stream and the main stream waits for its event, so it runs beside the previous
+        // frame's k_primary tail and k_resolve instead of behind them.  A blocking frame, or one whose inputs are still being uploaded on
+        // the main stream, classifies in line.
+        const bool ahead = defer && c->classify_ahead && !uploads_queued;
+        hipStream_t cs = ahead ? c->side : c->stream;
+        if (!c->classified) FT_HIP(c, hipEventCreateWithFlags(&c->classified, hipEventDisableTiming));
+        else FT_HIP(c, hipStreamWaitEvent(cs, c->classified, 0));  // one classification at a time, whichever streams they are on
+        if (ahead) {
+            // beside the previous frame's k_resolve (a bandwidth-bound kernel that leaves registers free), not beside the head of its
+            // k_primary: started as soon as it was queued, the classification took the first workgroup slots of a grid that fills the chip
+            // (measured: k_primary 226 -> 242 us, the 24 us merely moved)
+            const ft_context::FrameSlot& prev = c->slots[turn ^ 1];
+            if (c->classify_after_trace && prev.pending && prev.traced) FT_HIP(c, hipStreamWaitEvent(c->side, prev.traced, 0));
+            const ftk::Launch Ls{c->side, Lg.grid, 0, 0};
+            ftk::launch_classify(Ls, c->dev_scene, all, cls, jitter_extent, epoch, fc);
+            FT_HIP(c, hipEventRecord(c->classified, c->side));
+            FT_HIP(c, hipStreamWaitEvent(c->stream, c->classified, 0));
+            boundary_fresh = false;
+        } else {
+            timed(kStageOther, [&] { ftk::launch_classify(Lg, c->dev_scene, all, cls, jitter_extent, epoch, fc); });
+            FT_HIP(c, hipEventRecord(c->classified, c->stream));
+            boundary_fresh = false;
+        }
         ++n_launches;
     }
     if (!F.h_report) {
@@ -866,6 +955,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     }
     double* const out_rgb = q.format == 1 ? nullptr : c->d_out.as<double>();
     uint8_t* const out_rgba = q.format == 1 ? c->d_out8.as<uint8_t>() : nullptr;
+    const bool aside = defer && c->resolve_aside && !corner && timing < 2;   // queued frames: k_resolve on its own stream (blocking frames have nothing to hide it in)
     for (const Job& job : jobs) {
         const uint32_t n_pix = job.n_ids;
         const uint32_t n_samples = n_pix * (uint32_t)spp;
@@ -874,9 +964,12 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
                          (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
                          1.0 / (double)n_pix, 1.0 / (double)(corner ? res_h + 1 : res_h), nullptr, nullptr};
-        if (classify) { gen.counts = &fc->counts; gen.block_map = c->d_pos_block.as<uint32_t>(); }   // pix_base = job.id_base: the window's start in the active list
+        if (classify) { gen.counts = &fc->counts; gen.block_map = c->d_pos_block[turn].as<uint32_t>(); }   // pix_base = job.id_base: the window's start in the active list
         gen.group_log2 = (n_pix % 64u == 0u) ? group_log2 : 0;
-        timed(kStagePrimary, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], c->d_acc.as<double>(), n_samples, max_depth, fc); });
+        const int at = c->acc_turn;
+        double* const acc = c->d_acc[at].as<double>();
+        if (c->acc_busy[at]) { FT_HIP(c, hipStreamWaitEvent(c->stream, c->acc_free[at], 0)); c->acc_busy[at] = false; boundary_fresh = false; }   // a k_resolve on `tail` may still be reading this copy
+        timed(kStagePrimary, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], acc, n_samples, max_depth, fc); });
         ++n_launches;
         // Bounces >= 1: one k_bounce per level of the reflection tree, as many as the previous frame of this signature had (+ 1).
         // With "timing" = 1 the whole region is one bracket (kind shade): a bracket per launch costs more than a small level does.
@@ -885,25 +978,46 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         levels_launched = n_levels;
         auto bounces = [&](auto&& stage) {
             for (int b = 1; b <= n_levels; ++b) {
-                stage(kStageShade, [&] { ftk::launch_bounce(Lb, c->dev_scene, gen, rb[b & 1], rb[(b + 1) & 1], c->d_acc.as<double>(), n_samples, b, max_depth, b == n_levels && n_levels < last_bounce, fc); });
+                stage(kStageShade, [&] { ftk::launch_bounce(Lb, c->dev_scene, gen, rb[b & 1], rb[(b + 1) & 1], acc, n_samples, b, max_depth, b == n_levels && n_levels < last_bounce, fc); });
                 ++n_launches;
             }
         };
         if (timing >= 2) bounces(timed);
         else if (n_levels >= 1) timed(kStageShade, [&] { bounces([](int, auto&& fn) { fn(); }); });
-        if (corner) timed(kStageResolve, [&] { ftk::launch_resolve_corner(Lg, c->d_acc.as<double>(), n_samples, job.w, job.h, c->d_out_index.as<uint32_t>() + job.out_base, out_rgb, out_rgba); });
+        if (&job == &jobs.back()) {                                // (an event object of the slot's own: next_event's are re-used per frame as well)
+            if (!F.traced) FT_HIP(c, hipEventCreateWithFlags(&F.traced, hipEventDisableTiming));
+            FT_HIP(c, hipEventRecord(F.traced, c->stream));
+        }
+        if (!aside) for (int k = 0; k < 2; ++k) if (c->acc_busy[k]) {   // a queued frame's k_resolve may still be writing the frame on `tail`: frames reach d_out in order
+            FT_HIP(c, hipStreamWaitEvent(c->stream, c->acc_free[k], 0)); c->acc_busy[k] = false; boundary_fresh = false;
+        }
+        if (corner) timed(kStageResolve, [&] { ftk::launch_resolve_corner(Lg, acc, n_samples, job.w, job.h, c->d_out_index.as<uint32_t>() + job.out_base, out_rgb, out_rgba); });
         else {
             const bool last_job = &job == &jobs.back();            // the frame's last kernel hands the counters over (FrameReport)
-            ftk::ResolveArgs ra{c->d_acc.as<double>(), n_samples, classify ? &fc->counts : nullptr, job.id_base, n_pix, spp,
-                                classify ? c->d_pos_block.as<uint32_t>() : nullptr, (classify && n_chunks == 1) ? c->d_block_pos.as<int32_t>() : nullptr,
+            ftk::ResolveArgs ra{acc, n_samples, classify ? &fc->counts : nullptr, job.id_base, n_pix, spp,
+                                classify ? c->d_pos_block[turn].as<uint32_t>() : nullptr, (classify && n_chunks == 1 && !zeros_in_place) ? c->d_block_pos[turn].as<int32_t>() : nullptr,
                                 (uint32_t)(n_pix_total / 64), c->d_pixels.as<uint32_t>(), out_rgb, out_rgba, (uint32_t)gen.group_log2, fc, last_job ? F.d_report : nullptr};
-            timed(kStageResolve, [&] { ftk::launch_resolve(Lg, ra); });
-            if (last_job) c->fc_clean = true;
+            if (aside) {
+                // behind the chunk's tracing kernels, on its own stream: the main stream goes straight on with the next chunk or frame
+                hipEvent_t et = last_job ? F.traced : next_event(F);
+                if (!et) { c->err = "hipEventCreate failed"; return FT_ERR_HIP; }
+                if (!last_job) FT_HIP(c, hipEventRecord(et, c->stream));
+                FT_HIP(c, hipStreamWaitEvent(c->tail, et, 0));
+                ftk::Launch La = Lr; La.stream = c->tail;
+                ftk::launch_resolve(La, ra);
+                if (!c->acc_free[at]) FT_HIP(c, hipEventCreateWithFlags(&c->acc_free[at], hipEventDisableTiming));
+                FT_HIP(c, hipEventRecord(c->acc_free[at], c->tail));
+                c->acc_busy[at] = true;
+                c->acc_turn ^= 1;
+                boundary_fresh = false;
+            } else timed(kStageResolve, [&] { ftk::launch_resolve(Lr, ra); });
+            if (last_job) c->fc_clean[turn] = true;
         }
         ++n_launches;
     }
-    if (!c->fc_clean) { ftk::launch_report(Lg, fc, F.d_report); c->fc_clean = true; }   // corner frames end in k_resolve_corner: the hand-over is a launch of its own
-    if (boundary_fresh) ev1 = boundary;
+    if (!c->fc_clean[turn]) { ftk::launch_report(Lg, fc, F.d_report); c->fc_clean[turn] = true; }   // corner frames end in k_resolve_corner: the hand-over is a launch of its own
+    if (aside) { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->tail); }                  // the frame ends where its last k_resolve does
+    else if (boundary_fresh) ev1 = boundary;
     else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
     FT_HIP(c, hipGetLastError());
     F.signature = signature; F.levels_launched = levels_launched; F.last_bounce = last_bounce;
@@ -1054,14 +1168,14 @@ static int32_t debug_closest(ft_context* c, const double* origins, const double*
     double* din = c->d_dbg_in.as<double>();
     FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
-    c->fc_clean = false;
-    FT_HIP(c, hipMemsetAsync(c->d_fc.p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
+    c->fc_clean[0] = false;
+    FT_HIP(c, hipMemsetAsync(c->d_fc[0].p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
     double* dt = c->d_dbg_out.as<double>();
     double* dp = dt + N; double* dn = dp + 3 * N; double* dc = dn + 3 * N;
     int32_t* dh = reinterpret_cast<int32_t*>(dc + 3 * N);
     const size_t lds = lds_bytes_for(c->flat);
     ftk::Launch L{c->stream, c->n_cu * 4, lds, 0};
-    ftk::launch_debug_closest(L, c->dev_scene, din, din + 3 * N, (uint32_t)n, dh, dt, dp, dn, dc, c->d_fc.as<unsigned long long>());
+    ftk::launch_debug_closest(L, c->dev_scene, din, din + 3 * N, (uint32_t)n, dh, dt, dp, dn, dc, c->d_fc[0].as<unsigned long long>());
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipMemcpyAsync(t, dt, N * 8, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipMemcpyAsync(p, dp, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -1069,7 +1183,7 @@ static int32_t debug_closest(ft_context* c, const double* origins, const double*
     FT_HIP(c, hipMemcpyAsync(colour, dc, N * 24, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipMemcpyAsync(hit, dh, N * 4, hipMemcpyDeviceToHost, c->stream));
     unsigned long long n_overflow = 0;
-    FT_HIP(c, hipMemcpyAsync(&n_overflow, c->d_fc.p, sizeof n_overflow, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipMemcpyAsync(&n_overflow, c->d_fc[0].p, sizeof n_overflow, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipStreamSynchronize(c->stream));
     if (n_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
     return FT_OK;
@@ -1094,15 +1208,15 @@ static int32_t debug_blocked(ft_context* c, const double* origins, const double*
     FT_HIP(c, hipMemcpyAsync(din, origins, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 3 * N, dirs, N * 24, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(din + 6 * N, max_dist, N * 8, hipMemcpyHostToDevice, c->stream));
-    c->fc_clean = false;
-    FT_HIP(c, hipMemsetAsync(c->d_fc.p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
+    c->fc_clean[0] = false;
+    FT_HIP(c, hipMemsetAsync(c->d_fc[0].p, 0, sizeof(unsigned long long), c->stream));   // the overflow count of this query
     const size_t lds = lds_bytes_for(c->flat);
     ftk::Launch L{c->stream, c->n_cu * 4, lds, 0};
-    ftk::launch_debug_blocked(L, c->dev_scene, din, din + 3 * N, din + 6 * N, (uint32_t)n, c->d_dbg_out.as<int32_t>(), c->d_fc.as<unsigned long long>());
+    ftk::launch_debug_blocked(L, c->dev_scene, din, din + 3 * N, din + 6 * N, (uint32_t)n, c->d_dbg_out.as<int32_t>(), c->d_fc[0].as<unsigned long long>());
     FT_HIP(c, hipGetLastError());
     FT_HIP(c, hipMemcpyAsync(blocked, c->d_dbg_out.p, N * 4, hipMemcpyDeviceToHost, c->stream));
     unsigned long long n_overflow = 0;
-    FT_HIP(c, hipMemcpyAsync(&n_overflow, c->d_fc.p, sizeof n_overflow, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipMemcpyAsync(&n_overflow, c->d_fc[0].p, sizeof n_overflow, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipStreamSynchronize(c->stream));
     if (n_overflow) { c->err = "CSG hit list overflow"; return FT_ERR_OVERFLOW; }
     return FT_OK;
@@ -1133,27 +1247,23 @@ static int32_t debug_colour(ft_context* c, const double* origins, const double* 
         for (int k = 0; k < 3; ++k) { soa[(size_t)k * N + i] = origins[3 * i + k]; soa[(size_t)(3 + k) * N + i] = dirs[3 * i + k]; }
         soa[6 * N + i] = 1.0; slot[i] = (uint32_t)i;
     }
-    auto* fc = c->d_fc.as<ftk::FrameCounters>();
-    c->fc_clean = false;
+    auto* fc = c->d_fc[0].as<ftk::FrameCounters>();
+    c->fc_clean[0] = false;
     FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream));
     const ftk::RayBuf rb0 = ray_view(c->d_rays[0], c->ray_capacity), rb1 = ray_view(c->d_rays[1], c->ray_capacity);
     for (int k = 0; k < 7; ++k) FT_HIP(c, hipMemcpyAsync(c->d_rays[0].as<double>() + (size_t)k * cap, soa.data() + (size_t)k * N, N * 8, hipMemcpyHostToDevice, c->stream));
     FT_HIP(c, hipMemcpyAsync(rb0.slot, slot.data(), N * 4, hipMemcpyHostToDevice, c->stream));
     const uint32_t n_rays = (uint32_t)n;
     FT_HIP(c, hipMemcpyAsync(&fc->cc.n_rays[0], &n_rays, 4, hipMemcpyHostToDevice, c->stream));
-    FT_HIP(c, hipMemsetAsync(c->d_acc.p, 0, 3 * N * 8, c->stream));
+    FT_HIP(c, hipMemsetAsync(c->d_acc[0].p, 0, 3 * N * 8, c->stream));
     const size_t lds = lds_bytes_for(c->flat);
-    int variant = 0;
-    for (auto& m : c->flat.materials) if (needs_fancy(m)) variant |= 1;
-    for (auto& l : c->flat.lights) if (l.kind == ftd::LT_SOFT) variant |= 2;
-    if (!c->flat.meshes.empty()) variant |= 4;
-    ftk::Launch Lt{c->stream, c->n_cu * ftk::occupancy_blocks_bounce(lds, variant), lds, variant};
+    ftk::Launch Lt{c->stream, c->n_cu * c->blocks_bounce, lds, c->variant};
     ftk::Primary gen{};
     gen.pixel_ids = nullptr; gen.pix_base = 0; gen.n_pix = n_rays; gen.spp = 1; gen.inv_n_pix = 1.0 / (double)n_rays; gen.seed = 0ull; gen.counts = nullptr; gen.block_map = nullptr;
-    ftk::launch_bounce(Lt, c->dev_scene, gen, rb0, rb1, c->d_acc.as<double>(), n_rays, 0, max_depth, true, fc);   // level 0, followed to the end
+    ftk::launch_bounce(Lt, c->dev_scene, gen, rb0, rb1, c->d_acc[0].as<double>(), n_rays, 0, max_depth, true, fc);   // level 0, followed to the end
     FT_HIP(c, hipGetLastError());
     std::vector<double> planes(3 * N);
-    FT_HIP(c, hipMemcpyAsync(planes.data(), c->d_acc.p, 3 * N * 8, hipMemcpyDeviceToHost, c->stream));
+    FT_HIP(c, hipMemcpyAsync(planes.data(), c->d_acc[0].p, 3 * N * 8, hipMemcpyDeviceToHost, c->stream));
     struct { ftk::RenderCounters stats[ftk::kStatStripes]; } tail;
     FT_HIP(c, hipMemcpyAsync(&tail, &fc->stats[0], sizeof tail, hipMemcpyDeviceToHost, c->stream));
     FT_HIP(c, hipStreamSynchronize(c->stream));

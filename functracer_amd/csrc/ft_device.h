@@ -154,7 +154,8 @@ struct ResolveArgs {
     uint32_t group_log2;           // the chunk's slot numbering (Primary::group_log2)
     FrameCounters* fc; FrameReport* report;   // report non-null: the frame's last launch (see FrameReport; fc is cleared behind it)
 };
-void launch_resolve(const Launch& L, const ResolveArgs& a);
+void launch_resolve(const Launch& L, const ResolveArgs& a);   // L.grid: at most this many workgroups (occupancy_blocks_resolve() per CU: one resident round)
+int occupancy_blocks_resolve();
 void launch_report(const Launch& L, FrameCounters* fc, FrameReport* report);   // the same hand-over as a launch of its own (frames that end in another kernel)
 // CornerSampling.blendPixels (Image.fs:134-144) for a w x h rect whose (w+1) x (h+1) corner colours are in acc (one sample each).
 void launch_resolve_corner(const Launch& L, const double* acc, uint32_t acc_stride, uint32_t w, uint32_t h, const uint32_t* out_index, double* out_rgb, uint8_t* out_rgba);

@@ -2290,12 +2290,9 @@ void launch_bounce(const Launch& L, const DevScene& S, const Primary& gen, RayBu
 }
 void launch_resolve(const Launch& L, const ResolveArgs& a) {
     const uint32_t work = a.block_pos ? (a.n_blocks_total * 64u > a.n_pix_host ? a.n_blocks_total * 64u : a.n_pix_host) : a.n_pix_host;
-    // one resident round of workgroups (the grouped path holds 3 x 16 colours per lane: fewer waves fit than L.grid assumes), so that
-    // the hand-over at the end waits for one generation of workgroups, not for several
-    static int resident = 0;
-    if (!resident) { int n = 0; resident = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_resolve, kBlock, 0) == hipSuccess && n > 0) ? n : 2; }
-    const int cus = L.grid / 8;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, cus * resident)), dim3(kBlock), 0, L.stream, a);
+    // L.grid: one resident round of workgroups (occupancy_blocks_resolve x CUs; the grouped path holds 3 x 16 colours per lane: fewer waves fit
+    // than the tracing kernels' grids assume), so that the hand-over at the end waits for one generation of workgroups, not for several
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(work, L.grid)), dim3(kBlock), 0, L.stream, a);
 }
 #ifdef FT_ITEM_COUNTS
 extern "C" int ft_debug_item_counts(unsigned long long out[48], int reset) {      // [0..15] item counters, [16..47] section clocks, summed over the waves' slots
@@ -2332,6 +2329,10 @@ int occupancy_blocks_primary(size_t lds_bytes, int* variant) {
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, primary_variant(*variant), kBlock, lds_bytes) != hipSuccess) n = 1;
     return clamp_blocks(n);
+}
+int occupancy_blocks_resolve() {
+    int n = 0;
+    return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_resolve, kBlock, 0) == hipSuccess && n > 0) ? clamp_blocks(n) : 2;
 }
 int occupancy_blocks_bounce(size_t lds_bytes, int variant) {
     int n = 0;

@@ -884,6 +884,65 @@ def test_pipelined_frames_equal_blocking_frames(hip):
     assert hip.wait()["rays_traced"] == 0                         # nothing queued
 
 
+def test_zero_fill_skip_and_classification_ahead_change_no_pixel(hip):
+    """Two things a stream of frames does that a single frame does not: a queued frame's k_classify runs on a second stream
+    beside the frame before it, and Colour.Zero is not written again into blocks the last frame of the same signature (scene, camera,
+    size, pixel list) left zero.  The bunny covers a small part of the frame and the two cameras see it in different places, so a stale
+    zero (or a stale colour) from the frame before would show at once.  Every sequence must end in its last frame's blocking twin."""
+    p = _load("bunny")
+    p.lower(hip)
+    w, h, spp = 256, 192, 2
+    jit = ft.jitter_pattern(spp)
+    A = ft.make_camera((0.0, 0.9, -7.0), (0.6, 0.8, 0.0), (0, 1, 0), H.deg(40.0))
+    B = ft.make_camera((0.0, 0.9, -7.0), (-0.9, 0.6, 0.0), (0, 1, 0), H.deg(40.0))
+    for opt in ("zero_fill_skip", "classify_ahead"):
+        hip.set_option(opt, 0)
+    ref = {k: hip.render(c, w, h, spp, jit)[0] for k, c in (("A", A), ("B", B))}
+    ref8 = {k: hip.render_rgba8(c, w, h, spp, jit)[0] for k, c in (("A", A), ("B", B))}
+    left = [(0, 0, 128, 192)]
+    ref_left = hip.render(A, w, h, spp, jit, tiles=left)[0]
+    for opt in ("zero_fill_skip", "classify_ahead"):
+        hip.set_option(opt, 1)
+    seen = lambda img, cam: (np.abs(img).sum(axis=-1) > 0)
+    assert seen(ref["A"], A).any() and (seen(ref["A"], A) != seen(ref["B"], B)).any() and (~seen(ref["A"], A)).mean() > 0.5   # sparse, and differently so
+    cams = {"A": A, "B": B}
+    for seq in ("AA", "AB", "ABA", "BBAAB", "ABABAB", "AAAA"):
+        for name in seq:
+            hip.render_enqueue(cams[name], w, h, spp, jit)
+        hip.wait()
+        assert np.array_equal(hip.fetch_frame(np.zeros((h, w, 3))), ref[seq[-1]]), seq
+    for seq in ("aA", "AaA", "AbA", "bBbB", "AbaB", "aabb", "bAbA"):          # lower case: an RGBA8 frame in between (its own buffer, its own signature)
+        for name in seq:
+            hip.render_enqueue(cams[name.upper()], w, h, spp, jit, rgba8=name.islower())
+        hip.wait()
+        last = seq[-1]
+        if last.islower():
+            assert np.array_equal(hip.fetch_frame_rgba8(np.zeros((h, w, 4), dtype=np.uint8)), ref8[last.upper()]), seq
+        else:
+            assert np.array_equal(hip.fetch_frame(np.zeros((h, w, 3))), ref[last]), seq
+    # blocking calls, tiles in between (another pixel list: another signature) and the same camera again
+    for _ in range(2):
+        assert np.array_equal(hip.render(A, w, h, spp, jit)[0], ref["A"])
+    assert np.array_equal(hip.render(A, w, h, spp, jit, tiles=left)[0][:, :128], ref_left[:, :128])
+    assert np.array_equal(hip.render(A, w, h, spp, jit)[0], ref["A"])
+    assert np.array_equal(hip.render(B, w, h, spp, jit)[0], ref["B"])
+    # another scene under the same camera: the signature follows the commit
+    hip.clear()
+    hip.set_objects(hip.group([hip.translate((1.5, 1.0, 0.0), hip.primitive(ft.SPHERE))]))
+    hip.add_directional((0, -1, 1), (1, 1, 1))
+    hip.commit()
+    hip.set_option("zero_fill_skip", 0)
+    want = hip.render(B, w, h, spp, jit)[0]
+    hip.set_option("zero_fill_skip", 1)
+    p.lower(hip)
+    assert np.array_equal(hip.render(B, w, h, spp, jit)[0], ref["B"])
+    hip.clear()
+    hip.set_objects(hip.group([hip.translate((1.5, 1.0, 0.0), hip.primitive(ft.SPHERE))]))
+    hip.add_directional((0, -1, 1), (1, 1, 1))
+    hip.commit()
+    assert np.array_equal(hip.render(B, w, h, spp, jit)[0], want)
+
+
 def test_overflowing_hit_lists_grow_and_the_frame_still_matches(hip):
     """A mesh under CSG at a capacity of 2 hits: most lines through the bunny cross it more often.  The blocking call doubles the
     capacity until the lists hold every hit and delivers the oracle's frame; with "csg_auto_grow" off the same frame is refused
