@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--scene", default="bunny")
     ap.add_argument("--res", type=int, nargs=2, default=None)
     ap.add_argument("--spp", type=int, default=None)
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["auto", "headline", "config5", "weak"], default="auto",
                     help="which workload the K timed steps (and `value`) are: auto = headline at N = 1, config5 (strong) at N > 1")
@@ -320,6 +320,21 @@ def main():
     ctx.close()
 
 
+def effective_cpus():
+    """Host cores this process may really use: its affinity mask, capped by the cgroup's CPU quota (a GPU box of this pool shows 256
+    logical CPUs and grants 16 CPUs' worth of time; 256 threads on it are 16 cores' work and were reported as 256 in round 2)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(scene, res_h, res_v, spp, jitter, budget_s, gpu_frame):
     """The CPU oracle (a C++ port of the F# algorithm; the F# toolchain does not exist here) timed on this box's host cores on
     a bounded sample: interleaved 8-row bands of the same frame.  The bands it renders double as the parity check of the GPU
@@ -330,7 +345,7 @@ def cpu_baseline(scene, res_h, res_v, spp, jitter, budget_s, gpu_frame):
     from oracle import ft_oracle_py as O
     orc = O.Oracle()
     scene.lower(orc)
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     probe = tiling.bands_for_rank(res_h, res_v, 0, 64)             # calibrate on a thin sample, then size the real one to ~budget_s
     frame = np.zeros((res_v, res_h, 3))
     _, st = orc.render(scene.camera, res_h, res_v, spp, jitter, tiles=probe, threads=cores, out=frame)
@@ -339,7 +354,7 @@ def cpu_baseline(scene, res_h, res_v, spp, jitter, budget_s, gpu_frame):
     stride = max(1, int(round(1.0 / frac)))
     sample = tiling.bands_for_rank(res_h, res_v, 0, stride)
     _, st = orc.render(scene.camera, res_h, res_v, spp, jitter, tiles=sample, threads=cores, out=frame)
-    base = {"value": round(st["rays_traced"] / (st["wall_ms"] * 1e-3) / 1e6, 4), "unit": "Mrays/s", "cores": int(st["threads"]), "kind": "port",
+    base = {"value": round(st["rays_traced"] / (st["wall_ms"] * 1e-3) / 1e6, 4), "unit": "Mrays/s", "cores": int(st["threads"]), "logical_cpus_visible": os.cpu_count(), "kind": "port",
             "counts": "reference-equivalent rays (the oracle traces every ray of the F# recursion): compare with value_reference_equivalent",
             "sample": f"every {stride}th 8-row band of the same {res_h}x{res_v}x{spp}spp frame ({st['rays_traced']} rays, {st['wall_ms'] / 1e3:.1f} s), "
                       "C++ restatement of the F# algorithm (oracle/ft_oracle.cpp); the F# toolchain is unavailable"}

@@ -54,15 +54,17 @@ struct Material {          // Ray.fs:4-10; 64 bytes
     uint32_t pad;
 };
 
-// Scene.Texture (Scene.fs:47-53): a Grid under at most 5 uv functions, outermost (applied first) first.
-// 24 doubles.  op kind 0 = Texture.scale (u/a, v/b) (Texture.fs:14-16); kind 1 = Texture.rotate with
-// a = cos, b = sin of the angle (Texture.fs:18-22).
-struct Texture {             // Scene.Texture (Scene.fs:47-53) flattened; 192 bytes = 24 doubles
+// Scene.Texture (Scene.fs:47-53): a Grid or an Image under at most kMaxUvOps uv functions, outermost (applied first) first.
+// 48 doubles.  op kind 0 = Texture.scale (u/a, v/b) (Texture.fs:14-16); kind 1 = Texture.rotate with
+// a = cos, b = sin of the angle (Texture.fs:18-22).  (The reference nests TextureFunction without bound; its scenes use two at most.
+// The ops are read one by one through scalar loads, so their number costs the kernels nothing but the record's bytes.)
+constexpr int kMaxUvOps = 13;
+struct Texture {             // Scene.Texture (Scene.fs:47-53) flattened; 384 bytes = 48 doubles
     double c1[3], c2[3];     // Grid: the two colours.  Image: c1[0] = width, c1[1] = height
     double n_ops;
-    double ops[5][3];        // uv functions outermost first: {0, sx, sy} scale | {1, cos a, sin a} rotate
     double kind;             // 0 = Texture.grid, 1 = ImageTexture.image
     double pixel_base;       // Image: byte offset of its Rgb24 rows in DevScene::tex_pixels
+    double ops[kMaxUvOps][3];// uv functions outermost first: {0, sx, sy} scale | {1, cos a, sin a} rotate
 };
 
 enum LightKind : uint32_t { LT_DIRECTIONAL = 0, LT_SOFT = 1, LT_POINT = 2 };

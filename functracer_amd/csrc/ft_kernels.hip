@@ -76,7 +76,7 @@ struct Scene {
     cdp m2w;          // 12 per leaf
     cdp materials;    // 8 doubles per ftd::Material
     cdp lights;       // 12 doubles per ftd::Light
-    cdp textures;     // 24 doubles per ftd::Texture
+    cdp textures;     // 48 doubles per ftd::Texture
     cup program;
     cip meshes;       // 4 words per ftd::Mesh
     cdp nodes;        // 8 doubles per ftd::BspNode
@@ -93,7 +93,7 @@ struct Scene {
     cup item_pc;
     int32_t n_leaves, n_lights, csg_cap, stack_cap, n_items, n_cull_rows, csg_rows, lane_fold, n_simd;
 };
-static_assert(sizeof(Texture) == 192 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
+static_assert(sizeof(Texture) == 384 && sizeof(CullRecord) == 192 && sizeof(Leaf) == 128 && sizeof(Material) == 64 && sizeof(Light) == 96 && sizeof(Mesh) == 16 && sizeof(BspNode) == 64 && sizeof(BspLeaf) == 8, "flat layout");
 template <class DS> FT_DEV Scene scene_view(const DS& g) {
     Scene s;
     s.leaves = to_const_as(g.leaves); s.m2w = to_const_as(g.m2w);
@@ -1272,15 +1272,15 @@ FT_DEV Surface surface_at(const Scene& S, const Ray& rw, double t, uint32_t id0,
 // Wave-cooperative grab of the next 64-item batch from a persistent work cursor.
 // Texture.grid under its uv functions (Textures/Texture.fs:8-29), then the hueShift rotations that follow it.
 FT_DEV void textured_colour(const Scene& S, const MaterialV& mat, double u, double v, double col[3]) {
-    cdp T = S.textures + 24ull * (uint32_t)mat.texture;
+    cdp T = S.textures + 48ull * (uint32_t)mat.texture;
     const int n_ops = (int)T[6];
     for (int k = 0; k < n_ops; ++k) {
-        const double kind = T[7 + 3 * k], a = T[8 + 3 * k], b = T[9 + 3 * k];
+        const double kind = T[9 + 3 * k], a = T[10 + 3 * k], b = T[11 + 3 * k];
         if (kind == 0.0) { u = u / a; v = v / b; }
         else { const double x = a * u + 0.0 * 0.0 + b * v, z = -b * u + 0.0 * 0.0 + a * v; u = x; v = z; }
     }
     const double ru = fabs(u - floor(u)), rv = fabs(v - floor(v));                 // Texture.repeat
-    if (T[22] != 0.0) {                                                            // ImageTexture.image (Textures/Image.fs:27-35): nearest texel
+    if (T[7] != 0.0) {                                                             // ImageTexture.image (Textures/Image.fs:27-35): nearest texel
         const double w = T[0], h = T[1];
         const double x = floor(ru * w), y = floor(rv * h);
         // index = y*(3*width) + 3*x as the reference computes it (x == width wraps into the next row).  Past the last
@@ -1288,7 +1288,7 @@ FT_DEV void textured_colour(const Scene& S, const MaterialV& mat, double u, doub
         double idx = y * (3.0 * w) + 3.0 * x;
         const double last = 3.0 * (w * h - 1.0);
         idx = idx >= 0.0 ? (idx <= last ? idx : last) : 0.0;
-        const uint8_t* px = S.tex_pixels + (uint64_t)T[23] + (uint64_t)idx;
+        const uint8_t* px = S.tex_pixels + (uint64_t)T[8] + (uint64_t)idx;
         col[0] = (double)px[0] / 255.0; col[1] = (double)px[1] / 255.0; col[2] = (double)px[2] / 255.0;
     } else {
         const bool first = (ru < 0.5 && rv < 0.5) ? true : (ru < 0.5) ? false : (ru > 0.5 && rv > 0.5);

@@ -426,8 +426,20 @@ bool aabbIntersects(const Aabb& box, const Ray& ray) {                          
 }
 
 // ---------------------------------------------------------------- BspMesh.fs
+// (struct-of-arrays copy of a leaf's triangles: see triangleCandidates below)
+struct TriSoA {
+    std::vector<double> ax, ay, az, e1x, e1y, e1z, e2x, e2y, e2z;
+    void build(const std::vector<Tri>& ts) {
+        for (auto& t : ts) {
+            V3 e1 = psub(t.b, t.a), e2 = psub(t.c, t.a);
+            ax.push_back(t.a.x); ay.push_back(t.a.y); az.push_back(t.a.z);
+            e1x.push_back(e1.x); e1y.push_back(e1.y); e1z.push_back(e1.z); e2x.push_back(e2.x); e2y.push_back(e2.y); e2z.push_back(e2.z);
+        }
+    }
+};
 struct BspNode {                                                                 // BspMesh.fs:12-19
     bool isLeaf; std::vector<Tri> tris;       // Leaf of Geometry = group of triangles
+    TriSoA soa;
     Aabb aabb; std::unique_ptr<BspNode> left, right;
 };
 void optimalSplit(const Aabb& aabb, const std::vector<Tri>& tris, std::vector<Tri>& left, std::vector<Tri>& right) { // :30-46
@@ -442,7 +454,7 @@ void optimalSplit(const Aabb& aabb, const std::vector<Tri>& tris, std::vector<Tr
 }
 std::unique_ptr<BspNode> compile(int maxDepth, const std::vector<Tri>& tris) {   // BspMesh.fs:51-65
     auto node = std::make_unique<BspNode>();
-    auto makeLeaf = [&]() { node->isLeaf = true; node->tris = tris; };
+    auto makeLeaf = [&]() { node->isLeaf = true; node->tris = tris; node->soa.build(tris); };
     if (maxDepth == 0) { makeLeaf(); return node; }
     Aabb aabb = pointsBoundry(tris);
     std::vector<Tri> left, right;
@@ -454,9 +466,34 @@ std::unique_ptr<BspNode> compile(int maxDepth, const std::vector<Tri>& tris) {  
     node->right = compile(maxDepth - 1, right);
     return node;
 }
+// Speed only (the oracle doubles as bench.py's CPU baseline): the first two rejections of triangleHit - |a| < epsilon, u outside [0,1] -
+// evaluated for a whole leaf at once over a struct-of-arrays copy of its triangles, with exactly the operations triangleHit performs
+// (same products, same order, no contraction: the build has -ffp-contract=off), so that the compiler can use vector registers.  The
+// survivors go through triangleHit itself, from the top; a triangle this pass turns away is one triangleHit would have turned away at
+// the same comparison, so the hit sequence is unchanged bit for bit (tests/test_oracle_golden.py, tests/golden/frames.npz).
+__attribute__((target_clones("avx512f", "avx2", "default"), optimize("O3")))
+void triangleCandidates(const TriSoA& s, size_t n, const Ray& ray, unsigned char* keep) {
+    const double epsilon = 0.0000001;
+    const double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z, ox = ray.o.x, oy = ray.o.y, oz = ray.o.z;
+    const double *ax = s.ax.data(), *ay = s.ay.data(), *az = s.az.data(), *e1x = s.e1x.data(), *e1y = s.e1y.data(), *e1z = s.e1z.data(),
+                 *e2x = s.e2x.data(), *e2y = s.e2y.data(), *e2z = s.e2z.data();
+    for (size_t i = 0; i < n; ++i) {
+        const double hx = dy * e2z[i] - dz * e2y[i], hy = e2x[i] * dz - e2z[i] * dx, hz = dx * e2y[i] - dy * e2x[i];   // cross(ray.d, edge2)
+        const double a = e1x[i] * hx + e1y[i] * hy + e1z[i] * hz;                                                        // dot(edge1, hh)
+        const double f = 1.0 / a;
+        const double sx = ox - ax[i], sy = oy - ay[i], sz = oz - az[i];
+        const double u = f * (sx * hx + sy * hy + sz * hz);
+        keep[i] = !((a > -epsilon) & (a < epsilon)) & !((u < 0.0) | (u > 1.0));
+    }
+}
 void leafHits(const BspNode& n, const Ray& r, Hits& out) {                       // Leaf(triangles |> Seq.map triangle |> group), :53
     Hit h;
-    for (auto& t : n.tris) if (triangleHit(t, r, h)) out.push_back(h);
+    const size_t count = n.tris.size();
+    if (count < 16) { for (auto& t : n.tris) if (triangleHit(t, r, h)) out.push_back(h); return; }
+    static thread_local std::vector<unsigned char> keep;
+    if (keep.size() < count) keep.resize(count);
+    triangleCandidates(n.soa, count, r, keep.data());
+    for (size_t i = 0; i < count; ++i) if (keep[i] && triangleHit(n.tris[i], r, h)) out.push_back(h);
 }
 void bspIntersect(const BspNode& tree, const Ray& r, Hits& out) {                // BspMesh.fs:67-76 (tree is a Branch)
     if (!aabbIntersects(tree.aabb, r)) return;
@@ -652,9 +689,16 @@ Geometry build(fto_context* ctx, int id) {                                      
     }
 }
 
+// Speed only: a ray's hit list comes out of a per-thread pool instead of a fresh allocation (the recursion nests, so a pool, not one list).
+struct HitsLease {
+    static std::vector<Hits>& pool() { static thread_local std::vector<Hits> p; return p; }
+    Hits hits;
+    HitsLease() { auto& p = pool(); if (!p.empty()) { hits = std::move(p.back()); p.pop_back(); hits.clear(); } }
+    ~HitsLease() { pool().push_back(std::move(hits)); }
+};
 bool lightIsBlocked(fto_context* ctx, double maxDistance, const Ray& ray) {      // Scene.fs:119-121
     ctx->counters.shadow.fetch_add(1, std::memory_order_relaxed);
-    Hits hits;
+    HitsLease lease; Hits& hits = lease.hits;
     ctx->geometry(ray, hits);
     for (auto& i : hits) if (i.t >= 0.0 && i.t < maxDistance && i.material.applyLighting) return true;
     return false;
@@ -739,7 +783,7 @@ V3 shadeFragment(fto_context* ctx, int recursionLimit, const Fragment& f, const 
 
 V3 getColourForRay(fto_context* ctx, int recursionLimit, const Ray& ray, const Stream& st) {   // Shading.fs:131-139
     Ray offset{add(ray.o, scale(ray.d, 0.0001)), ray.d};                         // slightOffset, Shading.fs:129
-    Hits hits;
+    HitsLease lease; Hits& hits = lease.hits;
     ctx->geometry(offset, hits);
     Hit ix;
     if (!closest(hits, ix)) return {0, 0, 0};

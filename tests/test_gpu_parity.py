@@ -335,6 +335,26 @@ def test_textures_and_oren_nayar(hip):
     assert worst < 1e-6
 
 
+def test_thirteen_nested_texture_functions(hip):
+    """Scene.TextureFunction nests without bound in the reference (Scene.fs:47-53, 68-75); the flat texture record holds thirteen uv
+    functions (five until round 3).  A plane and a sphere under the full thirteen - scales and rotations alternating - against the oracle."""
+    ops = [(0, 1.1 + 0.05 * k, 0.9 - 0.03 * k) if k % 2 == 0 else (1, H.deg(17.0 + 9.0 * k), 0.0) for k in range(13)]
+    orc = O.Oracle()
+    for b in (orc, hip):
+        b.clear()
+        tex = lambda node: b.texture_grid((0.9, 0.2, 0.1), (0.1, 0.3, 0.8), ops, node)
+        b.set_objects(b.group([tex(b.translate((0, -1, 0), b.primitive(ft.PLANE))), tex(b.translate((0, 0.2, 0), b.primitive(ft.SPHERE)))]))
+        b.add_directional((0.3, -1, 0.6), (1, 1, 1))
+        b.commit()
+    cam = ft.make_camera((0, 1.5, -5), (0, 0, 0), (0, 1, 0), H.deg(50.0))
+    jit = ft.jitter_pattern(2)
+    want, _ = orc.render(cam, 160, 120, 2, jit)
+    got, _ = hip.render(cam, 160, 120, 2, jit)
+    assert H.assert_frames_match(got, want, what="13 uv functions") < 1e-6
+    o, d = H.random_rays(5000, seed=5, origin_scale=3.0, toward=(0, 0, 0), spread=2.0)
+    H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="13 uv functions")
+
+
 STOCHASTIC = [("night-house", 160, 90, 3), ("sample-soft", 96, 96, 4), ("repeat", 160, 90, 2), ("house", 160, 90, 2)]
 
 
@@ -664,6 +684,29 @@ def test_unclipped_bvh_fast_mode_stays_within_the_contract(hip):
     # triangle disagree about a grazing hit.  That is why the mode is opt-in and not the parity path.
     assert moved <= 0.005 * err.shape[0] * err.shape[1], moved
     assert np.median(err) < 1e-12
+
+
+def test_unclipped_bvh_equals_the_reference_at_depth_0(hip):
+    """What the fast mode computes IS a reference configuration: `bspMesh 0 file` - every original triangle, no clipping, brute force
+    (BspMesh.fs:95-97).  So the mode has an oracle: the device with "mesh_unclipped_bvh" = 1 on the depth-12 scene against the ORACLE
+    rendering the same PLY at depth 0, under the parity contract (1e-4 relative per channel, no pixel outside)."""
+    text = open(H.scene_path("bunny-bsp12")).read()
+    assert "bspMesh 12" in text
+    flat = ft.parse_scene(text.replace("bspMesh 12", "bspMesh 0"), os.path.join(H.ROOT, "scenes"))
+    deep = _load("bunny-bsp12")
+    orc = O.Oracle()
+    flat.lower(orc)
+    jit = ft.jitter_pattern(2)
+    want, wst = orc.render(deep.camera, 320, 180, 2, jit)
+    hip.set_option("mesh_unclipped_bvh", 1)
+    try:
+        deep.lower(hip)
+        assert hip.scene_info()["bsp_nodes"] == 0
+        got, st = hip.render(deep.camera, 320, 180, 2, jit)
+    finally:
+        hip.set_option("mesh_unclipped_bvh", 0)
+    worst = H.assert_frames_match(got, want, what="mesh_unclipped_bvh on bunny-bsp12 vs the oracle at bspMesh 0")
+    assert worst < 1e-6 and st["rays_reference_equivalent"] == wst["rays_traced"]
 
 
 def test_image_textures_match_oracle(hip):

@@ -136,7 +136,7 @@ def test_host_only_context_never_renders():
 def test_unsupported_surface_is_rejected_loudly():
     ctx = ft.Context(host_only=True)
     ctx.clear()
-    ops = [(0, 0.5, 0.5)] * 6                                # six nested texture functions: beyond the device path's fixed table
+    ops = [(0, 0.5, 0.5)] * 14                               # fourteen nested texture functions: beyond the device path's table of 13
     ctx.set_objects(ctx.group([ctx.texture_grid((1, 0, 0), (0, 1, 0), ops, ctx.primitive(ft.SPHERE))]))
     with pytest.raises(ft.FtError) as e:
         ctx.commit()
