@@ -17,6 +17,7 @@
 //                    4-wide nodes written into the ranges the flattener reserved for this mesh
 //   k_bvh_coarse     one thread: the level of the tree with at most 64 nodes, as float boxes rounded outward
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -168,10 +169,16 @@ __global__ __launch_bounds__(256) void k_bvh_fit(const double* __restrict__ tri_
     }
 }
 
+// What the emitters read of a finished hierarchy, whichever builder made it: internal node i (0 <= i < n_internal, root 0) covers the sorted
+// positions range_first[i] .. range_last[i], has box node_boxes[i] and children left[i] / right[i] (>= 0 an internal node, < 0 ~j: build
+// leaf j); build leaf j holds the positions leaf_first[j] .. + leaf_count[j] - 1 (at most kLeafTris of them) and has box leaf_boxes[j].
+// The linear BVH has one build leaf per triangle (j = its sorted position) and lets internal nodes of at most kLeafTris triangles stand
+// as leaves (scene_ref); the surface-area builder stops splitting at kLeafTris and makes those ranges build leaves itself.
 struct EmitArgs {
     const double* tris_in; uint32_t first_global; uint32_t n;
     const uint32_t* vals; const int32_t* left; const int32_t* right; const uint32_t* range_first; const uint32_t* range_last; const uint32_t* split_bit;
-    const double* tri_boxes; const double* node_boxes; const BuildState* st;
+    const double* leaf_boxes; const double* node_boxes; const BuildState* st;
+    const uint32_t* leaf_first; const uint32_t* leaf_count; const uint32_t* counts;   // counts[0] = n_internal, counts[1] = build leaves
     // outputs: the ranges reserved for this mesh in the scene's arrays
     BspNode* nodes; uint32_t node_base;        // n - 1 records
     BspLeaf* leaves; uint32_t leaf_base;       // (n - 1) + n records: internal node i as a leaf -> leaf_base + i; sorted triangle k alone -> leaf_base + n - 1 + k
@@ -179,7 +186,7 @@ struct EmitArgs {
     double* wide; uint32_t wide_base;          // n - 1 records of kWideNodeDoubles
 };
 __device__ __forceinline__ double pad_of(const BuildState* st) { return 1e-7 * unordered(st->extent) + 1e-300; }   // as the host builder: pruning can never drop a real hit
-__device__ __forceinline__ uint32_t range_size(const EmitArgs& a, int32_t ref) { return ref < 0 ? 1u : a.range_last[ref] - a.range_first[ref] + 1u; }
+__device__ __forceinline__ uint32_t range_size(const EmitArgs& a, int32_t ref) { return ref < 0 ? a.leaf_count[~ref] : a.range_last[ref] - a.range_first[ref] + 1u; }
 // The reference the traversal kernels use for build node `ref`: >= 0 a BspNode index, < 0 ~(BspLeaf index).
 __device__ __forceinline__ int32_t scene_ref(const EmitArgs& a, int32_t ref) {
     if (ref < 0) return ~(int32_t)(a.leaf_base + (a.n - 1u) + (uint32_t)~ref);
@@ -190,7 +197,7 @@ __device__ __forceinline__ int32_t wide_ref(const EmitArgs& a, int32_t ref) {
     return r < 0 ? r : (int32_t)(a.wide_base + (uint32_t)ref);
 }
 __device__ __forceinline__ void padded_box(const EmitArgs& a, int32_t ref, double pad, double out[6]) {
-    const double* b = ref >= 0 ? a.node_boxes + 6ull * (uint32_t)ref : a.tri_boxes + 6ull * a.vals[~ref];
+    const double* b = ref >= 0 ? a.node_boxes + 6ull * (uint32_t)ref : a.leaf_boxes + 6ull * (uint32_t)~ref;
     for (int k = 0; k < 3; ++k) { out[k] = b[k] - pad; out[3 + k] = b[3 + k] + pad; }
 }
 
@@ -203,9 +210,9 @@ __global__ __launch_bounds__(256) void k_bvh_emit(EmitArgs a) {
         double* O = a.tris_out + 9ull * (a.tri_base + i);
         for (int k = 0; k < 9; ++k) O[k] = T[k];
         a.tri_orig[a.tri_base + i] = a.first_global + src;
-        a.leaves[a.leaf_base + (a.n - 1u) + i] = BspLeaf{a.tri_base + i, 1u};
+        a.leaves[a.leaf_base + (a.n - 1u) + i] = i < a.counts[1] ? BspLeaf{a.tri_base + a.leaf_first[i], a.leaf_count[i]} : BspLeaf{0u, 0u};   // build leaf i
     }
-    if (i + 1u >= a.n) return;
+    if (i >= a.counts[0]) return;
     // internal node i: as a leaf (used when its range is small) and as binary / 4-wide nodes (used otherwise)
     a.leaves[a.leaf_base + i] = BspLeaf{a.tri_base + a.range_first[i], a.range_last[i] - a.range_first[i] + 1u};
     BspNode nd;
@@ -257,7 +264,7 @@ __global__ void k_bvh_coarse(EmitArgs a, float* __restrict__ coarse, uint32_t co
     }
     for (uint32_t k = 0; k < count; ++k) {
         const int32_t c = frontier[cur][k < nf ? k : nf - 1u];
-        const double* b = c >= 0 ? a.node_boxes + 6ull * (uint32_t)c : a.tri_boxes + 6ull * a.vals[~c];
+        const double* b = c >= 0 ? a.node_boxes + 6ull * (uint32_t)c : a.leaf_boxes + 6ull * (uint32_t)~c;
         for (int x = 0; x < 3; ++x) {
             const double lo = b[x], hi = b[3 + x];
             const double pad = 1e-5 * (fabs(lo) + fabs(hi) + (hi - lo)) + 1e-30;
@@ -266,25 +273,193 @@ __global__ void k_bvh_coarse(EmitArgs a, float* __restrict__ coarse, uint32_t co
     }
 }
 
+// The linear BVH's build leaves: sorted triangle k alone.
+__global__ __launch_bounds__(256) void k_bvh_single_leaves(const double* __restrict__ tri_boxes, const uint32_t* __restrict__ vals, uint32_t n, uint32_t* __restrict__ leaf_first,
+                                                            uint32_t* __restrict__ leaf_count, double* __restrict__ leaf_boxes, uint32_t* __restrict__ counts) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k == 0u) { counts[0] = n - 1u; counts[1] = n; }
+    if (k >= n) return;
+    leaf_first[k] = k; leaf_count[k] = 1u;
+    for (int a = 0; a < 6; ++a) leaf_boxes[6ull * k + a] = tri_boxes[6ull * vals[k] + a];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The surface-area builder: top down, a level of the tree per round, over the Morton-sorted triangles.  A node is a range of the
+// sorted order; a round (i) bins the centroids of every open node's triangles into kBins slabs of the node's box along each axis
+// (count and box per bin, device-scope atomics), (ii) prices the 3 x (kBins - 1) planes of every open node as
+// area(left) x count(left) + area(right) x count(right) and takes the cheapest, (iii) partitions every open node's range stably by
+// the side of its plane - one stable radix sort of the positions by (range start, side) - and (iv) opens the children that still
+// hold more than kLeafTris triangles.  A node no plane divides (coincident centroids), or one 28 levels down, is halved by position and
+// hands its own box to both halves.  The tree only decides which boxes a ray looks into: no pixel depends on it (ft_flat.h).
+constexpr int kBins = 16;
+constexpr uint32_t kBinWords = 7;                                    // ordered lo xyz, hi xyz, count
+struct SahState { uint32_t n_internal, n_leaves, level_begin, level_end, level, pad[3]; };
+
+__global__ void k_sah_begin(SahState* s, uint32_t n, uint32_t* range_first, uint32_t* range_last, double* node_boxes, const BuildState* st, int32_t* node_of, uint32_t* seg_first) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p == 0u) {
+        s->n_internal = 1u; s->n_leaves = 0u; s->level_begin = 0u; s->level_end = 1u; s->level = 0u;
+        range_first[0] = 0u; range_last[0] = n - 1u;
+        for (int a = 0; a < 3; ++a) { node_boxes[a] = unordered(st->lo[a]); node_boxes[3 + a] = unordered(st->hi[a]); }
+    }
+    if (p < n) { node_of[p] = 0; seg_first[p] = 0u; }
+}
+__global__ __launch_bounds__(256) void k_sah_clear_bins(const SahState* s, unsigned long long* bins) {
+    const uint32_t open = s->level_end - s->level_begin;
+    const unsigned long long words = (unsigned long long)open * 3u * kBins * kBinWords;
+    for (unsigned long long w = blockIdx.x * 256ull + threadIdx.x; w < words; w += (unsigned long long)gridDim.x * 256ull) {
+        const uint32_t f = (uint32_t)(w % kBinWords);
+        bins[w] = f < 3u ? ordered(__builtin_inf()) : f < 6u ? ordered(-__builtin_inf()) : 0ull;
+    }
+}
+__device__ __forceinline__ int bin_of(double c, double lo, double hi) {
+    const double w = hi - lo;
+    if (!(w > 0.0)) return 0;
+    const double u = (c - lo) / w * (double)kBins;
+    return u >= (double)(kBins - 1) ? kBins - 1 : (u > 0.0 ? (int)u : 0);
+}
+__global__ __launch_bounds__(256) void k_sah_bin(const SahState* s, uint32_t n, const uint32_t* __restrict__ vals, const int32_t* __restrict__ node_of,
+                                                  const double* __restrict__ tri_boxes, const double* __restrict__ node_boxes, unsigned long long* bins) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const int32_t o = node_of[p];
+    if (o < 0 || (uint32_t)o < s->level_begin) return;              // in a finished part of the tree
+    const double* tb = tri_boxes + 6ull * vals[p];
+    const double* nb = node_boxes + 6ull * (uint32_t)o;
+    unsigned long long* B = bins + (unsigned long long)((uint32_t)o - s->level_begin) * 3u * kBins * kBinWords;
+    for (int a = 0; a < 3; ++a) {
+        unsigned long long* w = B + (unsigned long long)(a * kBins + bin_of(0.5 * (tb[a] + tb[3 + a]), nb[a], nb[3 + a])) * kBinWords;
+        for (int k = 0; k < 3; ++k) { atomicMin(&w[k], ordered(tb[k])); atomicMax(&w[3 + k], ordered(tb[3 + k])); }
+        atomicAdd(&w[6], 1ull);
+    }
+}
+// One WAVE per open node (a thread per node spent the upper rounds of the tree reading 336 words one after the other): lane l < 48
+// holds bin l % 16 of axis l / 16, prefix and suffix unions run over the 16 lanes of an axis, lane b prices plane b of its axis, the
+// cheapest of the 45 wins; lane 0 makes the two children (an internal node or a build leaf each) and their boxes.
+struct BinBox { double lo[3], hi[3]; uint32_t cnt; };
+__device__ __forceinline__ BinBox shfl_box(const BinBox& b, int src) {
+    BinBox r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = __shfl(b.lo[k], src); r.hi[k] = __shfl(b.hi[k], src); }
+    r.cnt = __shfl(b.cnt, src);
+    return r;
+}
+__device__ __forceinline__ void unite(BinBox& a, const BinBox& b) { for (int k = 0; k < 3; ++k) { a.lo[k] = fmin(a.lo[k], b.lo[k]); a.hi[k] = fmax(a.hi[k], b.hi[k]); } a.cnt += b.cnt; }
+__device__ __forceinline__ double half_area(const BinBox& b) { const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2]; return dx * dy + dy * dz + dz * dx; }
+__global__ __launch_bounds__(256) void k_sah_split(SahState* s, const unsigned long long* __restrict__ bins, uint32_t* range_first, uint32_t* range_last, int32_t* left, int32_t* right,
+                                                   uint32_t* split_bit, uint32_t* plane, uint32_t* n_left, double* node_boxes, uint32_t* leaf_first, uint32_t* leaf_count) {
+    const uint32_t o = s->level_begin + blockIdx.x * 4u + threadIdx.x / 64u, lane = threadIdx.x & 63u;
+    if (o >= s->level_end) return;                                  // (whole waves leave together)
+    const double inf = __builtin_inf();
+    const uint32_t bin = lane % kBins;
+    BinBox mine{{inf, inf, inf}, {-inf, -inf, -inf}, 0u};
+    if (lane < 3u * kBins) {
+        const unsigned long long* w = bins + ((unsigned long long)(o - s->level_begin) * 3u * kBins + lane) * kBinWords;
+        mine.cnt = (uint32_t)w[6];
+        if (mine.cnt) for (int k = 0; k < 3; ++k) { mine.lo[k] = unordered(w[k]); mine.hi[k] = unordered(w[3 + k]); }
+    }
+    BinBox pre = mine, suf = mine;                                  // inclusive unions over bins [0, bin] and [bin, kBins) of the lane's axis
+    for (int d = 1; d < kBins; d <<= 1) {
+        const BinBox a = shfl_box(pre, (int)lane - d), b = shfl_box(suf, (int)lane + d);
+        if ((int)bin - d >= 0) unite(pre, a);
+        if ((int)bin + d < kBins) unite(suf, b);
+    }
+    const BinBox before = shfl_box(pre, (int)lane - 1);             // bins [0, bin): what lies left of plane `bin`
+    double cost = inf;
+    if (lane < 3u * kBins && bin >= 1u && before.cnt && suf.cnt && s->level < 28u) cost = half_area(before) * (double)before.cnt + half_area(suf) * (double)suf.cnt;
+    double best = cost; uint32_t who = lane;
+    for (int d = 32; d >= 1; d >>= 1) { const double c2 = __shfl_xor(best, d); const uint32_t w2 = __shfl_xor(who, d); if (c2 < best || (c2 == best && w2 < who)) { best = c2; who = w2; } }
+    const uint32_t first = range_first[o], size = range_last[o] - first + 1u;
+    const double* nb = node_boxes + 6ull * o;
+    BinBox lb, rb; uint32_t best_axis, best_plane, best_left;
+    if (!(best < inf)) {                                            // no plane divides the node: halves by position, each under the node's own box
+        best_axis = 3u; best_plane = 0u; best_left = size / 2u;
+        for (int k = 0; k < 3; ++k) { lb.lo[k] = rb.lo[k] = nb[k]; lb.hi[k] = rb.hi[k] = nb[3 + k]; }
+    } else {
+        best_axis = who / kBins; best_plane = who % kBins;
+        lb = shfl_box(before, (int)who); rb = shfl_box(suf, (int)who); best_left = lb.cnt;
+    }
+    if (lane != 0u) return;
+    split_bit[o] = best_axis == 3u ? 0u : best_axis; plane[o] = best_axis << 8 | best_plane; n_left[o] = best_left;
+    const uint32_t sizes[2] = {best_left, size - best_left}, firsts[2] = {first, first + best_left};
+    int32_t refs[2];
+    for (int c = 0; c < 2; ++c) {
+        if (sizes[c] > kLeafTris) {
+            const uint32_t id = atomicAdd(&s->n_internal, 1u);
+            range_first[id] = firsts[c]; range_last[id] = firsts[c] + sizes[c] - 1u;
+            const BinBox& bx = c == 0 ? lb : rb;
+            for (int k = 0; k < 3; ++k) { node_boxes[6ull * id + k] = bx.lo[k]; node_boxes[6ull * id + 3 + k] = bx.hi[k]; }
+            refs[c] = (int32_t)id;
+        } else {
+            const uint32_t j = atomicAdd(&s->n_leaves, 1u);
+            leaf_first[j] = firsts[c]; leaf_count[j] = sizes[c];
+            refs[c] = ~(int32_t)j;
+        }
+    }
+    left[o] = refs[0]; right[o] = refs[1];
+}
+// Sort key of every position: (start of its segment, side of its node's plane).  Positions outside the open nodes keep their place.
+__global__ __launch_bounds__(256) void k_sah_keys(const SahState* s, uint32_t n, const uint32_t* __restrict__ vals, const int32_t* __restrict__ node_of, const uint32_t* __restrict__ seg_first,
+                                                   const double* __restrict__ tri_boxes, const double* __restrict__ node_boxes, const uint32_t* __restrict__ plane,
+                                                   const uint32_t* __restrict__ n_left, const uint32_t* __restrict__ range_first, uint32_t* __restrict__ keys) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const int32_t o = node_of[p];
+    uint32_t side = 0u;
+    if (o >= 0 && (uint32_t)o >= s->level_begin) {
+        const uint32_t axis = plane[o] >> 8, b = plane[o] & 0xFFu;
+        if (axis == 3u) side = p - range_first[o] >= n_left[o] ? 1u : 0u;
+        else { const double* tb = tri_boxes + 6ull * vals[p]; const double* nb = node_boxes + 6ull * (uint32_t)o; side = (uint32_t)bin_of(0.5 * (tb[axis] + tb[3 + axis]), nb[axis], nb[3 + axis]) >= b ? 1u : 0u; }
+    }
+    keys[p] = seg_first[p] * 2u + side;
+}
+// After the partition: every position of an open node moves into the child that now covers it.
+__global__ __launch_bounds__(256) void k_sah_descend(const SahState* s, uint32_t n, int32_t* node_of, uint32_t* seg_first, const uint32_t* __restrict__ range_first,
+                                                      const uint32_t* __restrict__ n_left, const int32_t* __restrict__ left, const int32_t* __restrict__ right) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const int32_t o = node_of[p];
+    if (o < 0 || (uint32_t)o < s->level_begin) return;
+    const bool second = p - range_first[o] >= n_left[o];
+    const int32_t child = second ? right[o] : left[o];
+    node_of[p] = child >= 0 ? child : -1;
+    seg_first[p] = range_first[o] + (second ? n_left[o] : 0u);
+}
+__global__ void k_sah_next_level(SahState* s) { s->level_begin = s->level_end; s->level_end = s->n_internal; s->level += 1u; }
+__global__ __launch_bounds__(256) void k_sah_leaf_boxes(const SahState* s, const uint32_t* __restrict__ vals, const double* __restrict__ tri_boxes, const uint32_t* __restrict__ leaf_first,
+                                                         const uint32_t* __restrict__ leaf_count, double* __restrict__ leaf_boxes, uint32_t* __restrict__ counts, BuildState* st) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j == 0u) { counts[0] = s->n_internal; counts[1] = s->n_leaves; st->height = s->level; }   // rounds made = levels of internal nodes
+    if (j >= s->n_leaves) return;
+    double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()}, hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    for (uint32_t k = 0; k < leaf_count[j]; ++k) { const double* tb = tri_boxes + 6ull * vals[leaf_first[j] + k]; for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], tb[a]); hi[a] = fmax(hi[a], tb[3 + a]); } }
+    for (int a = 0; a < 3; ++a) { leaf_boxes[6ull * j + a] = lo[a]; leaf_boxes[6ull * j + 3 + a] = hi[a]; }
+}
+
 #define BVH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
 
 } // namespace
 
-// Build the BVH of triangles [first_global, first_global + n) of `tris` into the reserved ranges.  Returns hipSuccess, or an error;
+// Build the BVH of triangles [first_global, first_global + n) of `tris` into the reserved ranges: kind 0 the linear BVH, 1 the binned
+// surface-area tree (meshes beyond 4 Mi triangles get the linear one: a round's bins would not fit).  Returns hipSuccess, or an error;
 // *height receives the height of the binary tree in nodes (0: the mesh holds a non-finite coordinate and nothing was written).
-hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height) {
+hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height, int kind) {
     const uint32_t n = t.n;
+    const bool sah = kind == 1 && n <= (4u << 20);
     hipError_t err = hipSuccess;
     char* scratch = nullptr;
     void* sort_tmp = nullptr;
-    size_t sort_bytes = 0;
+    size_t sort_bytes = 0, sort_bytes2 = 0;
     *height = 0;
-    // scratch: state | tri boxes | node boxes | keys x2 | vals x2 | left right first last parent_node parent_leaf split arrived height
+    uint32_t key_bits = 1; while ((1ull << key_bits) < 2ull * n) ++key_bits;
+    // scratch: state | tri boxes | node boxes | keys x2 | vals x2 | left right first last parent_node parent_leaf split arrived height | leaves | (surface-area builder) ...
     const size_t n8 = ((size_t)n + 7) / 8 * 8;
+    const size_t open_max = (size_t)n / (kLeafTris + 1) + 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
     const size_t o_state = take(sizeof(BuildState)), o_tb = take(n8 * 48), o_nb = take(n8 * 48), o_k0 = take(n8 * 4), o_k1 = take(n8 * 4), o_v0 = take(n8 * 4), o_v1 = take(n8 * 4),
-                 o_l = take(n8 * 4), o_r = take(n8 * 4), o_f = take(n8 * 4), o_la = take(n8 * 4), o_pn = take(n8 * 4), o_pl = take(n8 * 4), o_sb = take(n8 * 4), o_ar = take(n8 * 4), o_h = take(n8 * 4);
+                 o_l = take(n8 * 4), o_r = take(n8 * 4), o_f = take(n8 * 4), o_la = take(n8 * 4), o_pn = take(n8 * 4), o_pl = take(n8 * 4), o_sb = take(n8 * 4), o_ar = take(n8 * 4), o_h = take(n8 * 4),
+                 o_lf = take(n8 * 4), o_lc = take(n8 * 4), o_lb = take(n8 * 48), o_cnt = take(16),
+                 o_sah = take(sizeof(SahState)), o_bins = take(sah ? open_max * 3 * kBins * kBinWords * 8 : 8);
     {
         BVH_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), off));
         BuildState* st = reinterpret_cast<BuildState*>(scratch + o_state);
@@ -295,17 +470,52 @@ hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height)
         uint32_t* rf = reinterpret_cast<uint32_t*>(scratch + o_f); uint32_t* rl = reinterpret_cast<uint32_t*>(scratch + o_la);
         int32_t* pn = reinterpret_cast<int32_t*>(scratch + o_pn); int32_t* pl = reinterpret_cast<int32_t*>(scratch + o_pl);
         uint32_t* sb = reinterpret_cast<uint32_t*>(scratch + o_sb); uint32_t* ar = reinterpret_cast<uint32_t*>(scratch + o_ar); uint32_t* hh = reinterpret_cast<uint32_t*>(scratch + o_h);
+        uint32_t* lf = reinterpret_cast<uint32_t*>(scratch + o_lf); uint32_t* lc = reinterpret_cast<uint32_t*>(scratch + o_lc); double* lb = reinterpret_cast<double*>(scratch + o_lb);
+        uint32_t* counts = reinterpret_cast<uint32_t*>(scratch + o_cnt);
+        SahState* ss = reinterpret_cast<SahState*>(scratch + o_sah);
+        unsigned long long* bins = reinterpret_cast<unsigned long long*>(scratch + o_bins);
         const dim3 grid((n + 255u) / 256u), block(256);
         hipLaunchKernelGGL(k_bvh_init, dim3(1), dim3(1), 0, stream, st);
         hipLaunchKernelGGL(k_bvh_prepare, grid, block, 0, stream, t.tris, t.first_global, n, tb, st);
         hipLaunchKernelGGL(k_bvh_morton, grid, block, 0, stream, tb, n, st, k0, v0);
         BVH_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, k0, k1, v0, v1, n, 0, 30, stream));
+        if (sah) { BVH_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes2, k0, k1, v0, v1, n, 0, key_bits, stream)); if (sort_bytes2 > sort_bytes) sort_bytes = sort_bytes2; }
         BVH_HIP(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 16));
         BVH_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, k0, k1, v0, v1, n, 0, 30, stream));
-        BVH_HIP(hipMemsetAsync(ar, 0, n8 * 4, stream));
-        hipLaunchKernelGGL(k_bvh_hierarchy, grid, block, 0, stream, k1, n, left, right, rf, rl, pn, pl, sb);
-        hipLaunchKernelGGL(k_bvh_fit, grid, block, 0, stream, tb, v1, n, left, right, pn, pl, ar, nb, hh, st);
-        const EmitArgs ea{t.tris, t.first_global, n, v1, left, right, rf, rl, sb, tb, nb, st,
+        const uint32_t* vals = v1;                                  // sorted position -> triangle of the mesh
+        if (!sah) {
+            BVH_HIP(hipMemsetAsync(ar, 0, n8 * 4, stream));
+            hipLaunchKernelGGL(k_bvh_hierarchy, grid, block, 0, stream, k1, n, left, right, rf, rl, pn, pl, sb);
+            hipLaunchKernelGGL(k_bvh_fit, grid, block, 0, stream, tb, v1, n, left, right, pn, pl, ar, nb, hh, st);
+            hipLaunchKernelGGL(k_bvh_single_leaves, grid, block, 0, stream, tb, v1, n, lf, lc, lb, counts);
+        } else {
+            // the Morton order is where the rounds start: neighbours in space are neighbours in the arrays the atomics of a round hit
+            int32_t* node_of = pn; uint32_t* seg_first = reinterpret_cast<uint32_t*>(pl); uint32_t* plane = ar; uint32_t* n_left = hh;   // (the linear builder's arrays, unused here)
+            uint32_t *vin = v1, *vout = v0, *kin = k0, *kout = k1;
+            BVH_HIP(hipMemsetAsync(left, 0, n8 * 4, stream)); BVH_HIP(hipMemsetAsync(right, 0, n8 * 4, stream));
+            BVH_HIP(hipMemsetAsync(rf, 0, n8 * 4, stream)); BVH_HIP(hipMemsetAsync(rl, 0, n8 * 4, stream)); BVH_HIP(hipMemsetAsync(sb, 0, n8 * 4, stream));
+            hipLaunchKernelGGL(k_sah_begin, grid, block, 0, stream, ss, n, rf, rl, nb, st, node_of, seg_first);
+            for (int round = 0; round < 64; ++round) {
+                SahState h{};
+                BVH_HIP(hipMemcpyAsync(&h, ss, sizeof h, hipMemcpyDeviceToHost, stream));
+                BVH_HIP(hipStreamSynchronize(stream));
+                const uint32_t open = h.level_end - h.level_begin;
+                if (open == 0u) break;
+                if (open > open_max) { err = hipErrorInvalidValue; goto done; }   // (cannot happen: every open node holds more than kLeafTris triangles)
+                const uint32_t words_blocks = (uint32_t)std::min<unsigned long long>(((unsigned long long)open * 3u * kBins * kBinWords + 255u) / 256u, 4096ull);
+                hipLaunchKernelGGL(k_sah_clear_bins, dim3(words_blocks), block, 0, stream, ss, bins);
+                hipLaunchKernelGGL(k_sah_bin, grid, block, 0, stream, ss, n, vin, node_of, tb, nb, bins);
+                hipLaunchKernelGGL(k_sah_split, dim3((open + 3u) / 4u), block, 0, stream, ss, bins, rf, rl, left, right, sb, plane, n_left, nb, lf, lc);
+                hipLaunchKernelGGL(k_sah_keys, grid, block, 0, stream, ss, n, vin, node_of, seg_first, tb, nb, plane, n_left, rf, kin);
+                BVH_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, kin, kout, vin, vout, n, 0, key_bits, stream));
+                { uint32_t* x = vin; vin = vout; vout = x; }
+                hipLaunchKernelGGL(k_sah_descend, grid, block, 0, stream, ss, n, node_of, seg_first, rf, n_left, left, right);
+                hipLaunchKernelGGL(k_sah_next_level, dim3(1), dim3(1), 0, stream, ss);
+            }
+            vals = vin;
+            hipLaunchKernelGGL(k_sah_leaf_boxes, grid, block, 0, stream, ss, vals, tb, lf, lc, lb, counts, st);
+        }
+        const EmitArgs ea{t.tris, t.first_global, n, vals, left, right, rf, rl, sb, lb, nb, st, lf, lc, counts,
                           t.nodes, t.node_base, t.leaves, t.leaf_base, t.tris, t.tri_orig, t.tri_base, t.wide, t.wide_base};
         hipLaunchKernelGGL(k_bvh_emit, grid, block, 0, stream, ea);
         if (t.coarse_count) hipLaunchKernelGGL(k_bvh_coarse, dim3(1), dim3(64), 0, stream, ea, t.coarse, t.coarse_count);

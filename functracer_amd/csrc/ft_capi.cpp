@@ -29,7 +29,7 @@ enum { kStageOther = 0, kStageClosest = 1, kStageShade = 2, kStageResolve = 3, k
 // What a frame copies back when it retires: FrameCounters from `stats` to its end.
 static_assert(sizeof(ftk::FrameCounters) % 16 == 0 && offsetof(ftk::RenderCounters, ref_equiv) == 32, "the hand-over at the end of a frame copies words and clears 16 bytes at a time");
 
-constexpr int64_t kDeviceBvhMinTris = 4096;   // "bvh_builder" = 2: smaller meshes get the host's SAH tree (a few ms at most), larger ones the device's linear BVH
+constexpr int64_t kDeviceBvhMinTris = 4096;   // "bvh_builder" = 2: smaller meshes get the host's swept SAH tree (a few ms at most), larger ones the device's binned one
 struct ft_context {
     std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
     bool host_only = false;
@@ -41,9 +41,9 @@ struct ft_context {
     fth::SceneGraph graph;
     fth::FlatScene flat;
     bool committed = false;
-    int bvh_builder = 2;            // who builds the exact BVH of top-level-Leaf meshes: 1 = the device (ft_bvh.hip: linear BVH), 0 = the host (surface-area
-                                    // sweep), 2 = by size: the host's tree traces 7-11 % faster and takes 1.2 ms for 980 triangles but 177 ms for 69.6 K,
-                                    // the device's 0.4 and 8 ms, so meshes of kDeviceBvhMinTris triangles and more are built on the device
+    int bvh_builder = 2;            // who builds the exact BVH of top-level-Leaf meshes: 0 = the host (swept surface-area split: the best tree, 1.2 ms for 980
+                                    // triangles but 160 ms for 69.6 K), 1 = the device's linear BVH (ft_bvh.hip: ~1 ms, traces ~9 % slower), 3 = the device's
+                                    // binned surface-area tree over the Morton order, 2 = by size: the host's below kDeviceBvhMinTris triangles, 3's from there on
     double commit_ms[4] = {0, 0, 0, 0};   // last ft_scene_commit: flatten on the host, device BVH builds, uploads + the rest, BVH height (not a time)
 
     int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
@@ -326,7 +326,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "csg_auto_grow")) { c->csg_auto_grow = value != 0; return FT_OK; }
     if (!std::strcmp(key, "follow_below")) { if (value < -1) return FT_ERR_INVALID; c->follow_below = value; c->staged_hint = -1; for (ft_context* p : c->peers) { p->follow_below = value; p->staged_hint = -1; } return FT_OK; }
     if (!std::strcmp(key, "level_hint")) { c->level_hint = value != 0; for (ft_context* p : c->peers) p->level_hint = value != 0; return FT_OK; }
-    if (!std::strcmp(key, "bvh_builder")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->bvh_builder = (int)value; c->committed = false; return FT_OK; }
+    if (!std::strcmp(key, "bvh_builder")) { if (value < 0 || value > 3) return FT_ERR_INVALID; c->bvh_builder = (int)value; c->committed = false; return FT_OK; }
     if (!std::strcmp(key, "mesh_unclipped_bvh")) { c->graph.mesh_unclipped_bvh = value != 0; c->committed = false; return FT_OK; }
     c->err = std::string("unknown option: ") + key;
     return FT_ERR_INVALID;
@@ -440,7 +440,7 @@ int32_t ft_scene_commit(ft_context* c) {
     // back to the host's builder, once, for the whole scene.
     for (int attempt = 0; attempt < 2; ++attempt) {
         c->graph.device_bvh = !c->host_only && c->bvh_builder >= 1 && attempt == 0;
-        c->graph.device_bvh_min_tris = c->bvh_builder == 2 ? kDeviceBvhMinTris : 0;
+        c->graph.device_bvh_min_tris = c->bvh_builder == 2 ? kDeviceBvhMinTris : 0;   // 1: the device's linear BVH, 3: its surface-area tree, whatever the size
         auto t0 = clock::now();
         int32_t rc = c->graph.flatten(c->flat, c->err);
         c->commit_ms[0] += ms_since(t0);
@@ -501,7 +501,7 @@ static int32_t upload_scene(ft_context* c) {
             const ftk::LbvhTarget t{c->d_tris.as<double>(), j.first_global, j.n, c->d_nodes.as<ftd::BspNode>(), j.node_base, c->d_bleaves.as<ftd::BspLeaf>(), j.leaf_base,
                                     c->d_tri_orig.as<uint32_t>(), j.tri_base, c->d_wide.as<double>(), j.wide_base, c->d_coarse.as<float>() + 6 * (size_t)j.coarse_first, j.coarse_count};
             uint32_t height = 0;
-            FT_HIP(c, ftk::build_lbvh(c->stream, t, &height));
+            FT_HIP(c, ftk::build_lbvh(c->stream, t, &height, c->bvh_builder == 1 ? 0 : 1));
             // height 0: a non-finite coordinate; > 40: deeper than the packet walk's 64-entry stack allows (3 entries per 4-wide level)
             if (height == 0 || height > 40) { c->err = "device BVH build refused (non-finite vertex or a tree deeper than 40 levels): the host builder takes over"; return FT_ERR_BUILD; }
             tallest = std::max(tallest, height);

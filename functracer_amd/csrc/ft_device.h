@@ -171,7 +171,7 @@ struct LbvhTarget {
     double* wide; uint32_t wide_base;
     float* coarse; uint32_t coarse_count;
 };
-hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height);
+hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height, int kind = 1);   // kind 0: linear BVH, 1: binned surface-area tree over the Morton order
 
 // Debug: closest hit / blocked for arbitrary rays (no slightOffset).
 void launch_debug_closest(const Launch& L, const DevScene& S, const double* o, const double* d, uint32_t n,

@@ -147,8 +147,11 @@ const char* ft_last_error(const ft_context* ctx);
  * cannot reach any object are finished before any ray is generated; the bundle is bounded from the jitter pattern handed to ft_render, whatever its range), "level_hint" (default 1: a frame launches as many levels of the reflection tree as the
  * previous frame of the same scene, size and samples had rays in, plus one, whose rays are followed to the end inside the launch; 0: always max_depth levels), "follow_below" (levels in which that
  * previous frame had no more rays than this are not worth a launch and are followed as well; -1 = default: two rays per SIMD of the device; 0: every level that had a ray), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
- * differ from the reference-shaped clipped BSP in the last bits), "bvh_builder" (who builds the exact BVH of top-level-Leaf meshes at commit - 1: the device, a linear BVH; 0: the host, a
- * surface-area sweep (a better tree, a much slower build); 2 = default: the host below 4096 triangles, the device from there on), "wave_samples" (0 = default, 16: a bounce-0 wavefront takes up to that many jitter offsets of 64 / that many pixels of an
+ * differ from the reference-shaped clipped BSP in the last bits), "bvh_builder" (who builds the exact BVH of top-level-Leaf meshes at commit - 0: the host, a swept
+ * surface-area split (the best tree, a slow build: 160 ms for 70 K triangles); 1: the device, a linear BVH (1 ms, traces ~9 % slower); 3: the device, a binned surface-area tree
+ * over the Morton order (7 ms, traces like the host's); 2 = default: the host below 4096 triangles, the device's surface-area tree from there on),
+ * "classify_ahead" / "resolve_aside" / "zero_fill_skip" (1 = default: what a stream of queued frames does that a single frame cannot - the next frame's k_classify on a second
+ * stream, k_resolve on a third with the sample colours double-buffered, Colour.Zero not written again into blocks the last frame of the same signature left zero; 0 switches each off), "wave_samples" (0 = default, 16: a bounce-0 wavefront takes up to that many jitter offsets of 64 / that many pixels of an
  * 8x8 block when the sample count has the power of two in it - a narrower bundle; 1, 2, 4, 8, 16; no pixel depends on it).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
 
@@ -183,7 +186,7 @@ int32_t ft_scene_add_soft_directional(ft_context* ctx, const double dir[3], int3
 int32_t ft_scene_add_positional(ft_context* ctx, const double pos[3], const double falloff[3],
                                 const double colour[3]);
 /* Flatten the graph, build BSP trees (BspMesh.compile, BspMesh.fs:51-65) and upload to HBM.  The exact BVH that stands in for the
- * linear scan of a `bspMesh 0` (BspMesh.fs:95-97) is built on the device ("bvh_builder" = 1, default) or by the host (0). */
+ * linear scan of a `bspMesh 0` (BspMesh.fs:95-97) is built by the host below 4096 triangles and on the device from there on ("bvh_builder" = 2, default). */
 int32_t ft_scene_commit(ft_context* ctx);
 /* Wall time of the last ft_scene_commit in ms: [0] flatten on the host (includes the host's BVH builds with "bvh_builder" = 0),
  * [1] BVH builds on the device, [2] uploads and the rest; [3] is not a time: the height of the tallest device-built tree. */

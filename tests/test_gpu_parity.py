@@ -605,7 +605,7 @@ def test_device_built_bvh_equals_host_built_bvh(hip):
     jit = ft.jitter_pattern(2)
     results = {}
     try:
-        for builder in (0, 1, 2):
+        for builder in (0, 1, 2, 3):
             hip.set_option("bvh_builder", builder)
             hip.clear()
             hip.set_objects(hip.group([hip.material(hip.bsp_mesh(0, tris.reshape(-1, 9)), colour=(0.9, 0.5, 0.2), shineyness=4.0)]))
@@ -613,7 +613,7 @@ def test_device_built_bvh_equals_host_built_bvh(hip):
             hip.add_positional((2, 3, -2), (1, 0.1, 0.01), (0.5, 0.5, 1.0))
             hip.commit()
             ct = hip.commit_times()
-            assert (ct["device_bvh_height"] > 0) == (builder == 1) and (ct["device_bvh_ms"] > 0) == (builder == 1)   # 3000 triangles: the default asks the host
+            assert (ct["device_bvh_height"] > 0) == (builder in (1, 3)) and (ct["device_bvh_ms"] > 0) == (builder in (1, 3))   # 3000 triangles: the default asks the host
             results[builder] = (hip.closest(o, d), hip.blocked(o, d, md), hip.render(cam, 320, 240, 2, jit)[0])
         big = np.concatenate([tris, tris[:1500] + 0.01])            # 4500 triangles: past the default's threshold
         hip.clear()
@@ -630,6 +630,9 @@ def test_device_built_bvh_equals_host_built_bvh(hip):
     for x, y in zip(c0, results[2][0]):
         assert np.array_equal(x, y)
     assert np.array_equal(b0, results[2][1]) and np.array_equal(f0, results[2][2])
+    for x, y in zip(c0, results[3][0]):                             # the device's binned surface-area tree
+        assert np.array_equal(x, y)
+    assert np.array_equal(b0, results[3][1]) and np.array_equal(f0, results[3][2])
     orc = O.Oracle()
     orc.clear()
     orc.set_objects(orc.group([orc.material(orc.bsp_mesh(0, tris.reshape(-1, 9)), colour=(0.9, 0.5, 0.2), shineyness=4.0)]))

@@ -21,7 +21,7 @@ for name, spp, unclipped in CASES:
     p = ft.parse_scene_file(os.path.join(R, "scenes", name + ".scene"))
     jit = ft.jitter_pattern(spp)
     frames = {}
-    for builder in (0, 1):
+    for builder in (0, 1, 3):
         ctx.set_option("mesh_unclipped_bvh", unclipped)
         ctx.set_option("bvh_builder", builder)
         commits = []
@@ -38,14 +38,14 @@ for name, spp, unclipped in CASES:
         ctx.fetch_frame(f)
         frames[builder] = f
         c = min(commits, key=lambda q: q["lower_and_commit_ms"])
-        row = {"builder": "device LBVH" if builder else "host surface-area sweep", "triangles": ctx.scene_info()["triangles"],
+        row = {"builder": {0: "host surface-area sweep", 1: "device linear BVH", 3: "device binned surface-area tree"}[builder], "triangles": ctx.scene_info()["triangles"],
                "commit": {k: round(v, 3) if isinstance(v, float) else v for k, v in c.items()}, "frame_kernel_ms": round(best["kernel_ms"], 3),
                "k_primary_ms": round(kt["primary"]["ms"], 3), "rays_traced": best["rays_traced"]}
         out[f"{name} builder={builder}"] = row
         print(name, json.dumps(row), flush=True)
-    same = bool(np.array_equal(frames[0], frames[1]))
+    same = bool(np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[3]))
     out[f"{name} frames_identical"] = same
-    print(name, "frames identical across builders:", same, "max abs diff", float(np.abs(frames[0] - frames[1]).max()), flush=True)
+    print(name, "frames identical across builders:", same, "max abs diff", float(max(np.abs(frames[0] - frames[1]).max(), np.abs(frames[0] - frames[3]).max())), flush=True)
 ctx.set_option("mesh_unclipped_bvh", 0)
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(R, "gpurun_out", "bvh_compare.json"), "w"), indent=1)
