@@ -15,7 +15,7 @@ from . import _capi
 from ._capi import (CIRCLE, CONE, CUBE, CYLINDER, EXCLUDE, INTERSECT, PLANE, SOLID_CYLINDER, SPHERE, SQUARE, SUBTRACT, UNION,
                     FtError, SceneBuilder, make_camera)
 
-__all__ = ["Context", "ParsedScene", "parse_scene", "parse_scene_file", "jitter_pattern", "quantise_rgba8", "write_png",
+__all__ = ["Context", "PinnedArray", "ParsedScene", "parse_scene", "parse_scene_file", "jitter_pattern", "quantise_rgba8", "write_png",
            "parse_colour", "parse_ply", "FtError", "make_camera", "HIP_LIB", "HOST_LIB", "DEFAULT_SEED"]
 
 HIP_LIB = os.environ.get("FT_HIP_LIB") or os.path.join(_capi.LIB_DIR, "libfunctracer_hip.so")   # FT_HIP_LIB: experimental builds
@@ -53,9 +53,11 @@ def hip_lib():
         lib.ft_debug_colour.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_double_p, C.c_int64, C.c_int32, _capi.c_double_p]
         lib.ft_get_commit_times.argtypes = [C.c_void_p, _capi.c_double_p]
         lib.ft_debug_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        lib.ft_debug_devices.argtypes = [C.c_void_p, _capi.c_int32_p, C.c_int32]
         lib.ft_debug_slice.argtypes = [_capi.c_double_p] * 4 + [_capi.c_int32_p, _capi.c_double_p, _capi.c_int32_p]
         lib.ft_render_enqueue.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32, C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32]
         lib.ft_render_wait.argtypes = [C.c_void_p, C.POINTER(_capi.ft_stats)]
+        lib.ft_render_enqueue_into.argtypes = [C.c_void_p, C.POINTER(_capi.ft_camera), C.c_int32, C.c_int32, C.c_int32, _capi.c_double_p, C.c_int32, C.c_uint64, C.POINTER(_capi.ft_rect), C.c_int32, C.c_int32, C.c_void_p]
         lib.ft_get_kernel_times.argtypes = [C.c_void_p, _capi.c_double_p, _capi.c_int32_p]
         lib.ft_quantise_rgba8.argtypes = [_capi.c_double_p, C.c_int64, C.POINTER(C.c_uint8)]
         _hip = lib
@@ -185,6 +187,30 @@ def load_image(path):
     return out.reshape(h.value, w.value, 3)
 
 
+class PinnedArray:
+    """A numpy array over page-locked host memory from ft_host_alloc: frames copied into it arrive by one DMA at link rate
+    (`with ft.PinnedArray((h, w, 3)) as frame: ctx.render(..., out=frame)`)."""
+
+    def __init__(self, shape, dtype=np.float64):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = hip_lib().ft_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError(f"ft_host_alloc({self.nbytes}) failed")
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self._p), dtype=dtype).reshape(shape)
+
+    def __enter__(self):
+        return self.array
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self._p:
+            self.array = None
+            hip_lib().ft_host_free(self._p)
+            self._p = None
+
+
 class Context(SceneBuilder):
     """One ft_context on one MI355X.  `host_only=True` gives the test hook that can build and flatten
     scenes but never renders."""
@@ -251,10 +277,16 @@ class Context(SceneBuilder):
         self._check(self._lib.ft_fetch_frame_rgba8(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
-    def render_enqueue(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None, rgba8=False):
-        """ft_render_enqueue[_rgba8]: queue a frame and return; `wait()` retires what is queued."""
+    def render_enqueue(self, camera, res_h, res_v, spp, jitter, max_depth=MAX_DEPTH, seed=DEFAULT_SEED, tiles=None, rgba8=False, out=None):
+        """ft_render_enqueue[_rgba8]: queue a frame and return; `wait()` retires what is queued.  With `out` (a PinnedArray's array, or any
+        C-contiguous array of the frame's shape that outlives the frame) the copy to the host is queued behind the frame: ft_render_enqueue_into."""
         jitter = np.zeros((1, 2)) if spp == 0 else _capi.as_f64(jitter, (spp, 2))
         rects, n_rects = _capi.make_rects(tiles)
+        if out is not None:
+            assert out.flags["C_CONTIGUOUS"] and out.nbytes == res_h * res_v * (4 if rgba8 else 24)
+            self._check(self._lib.ft_render_enqueue_into(self._ctx, C.byref(camera), res_h, res_v, spp, _capi.dptr(jitter), max_depth, int(seed), rects, n_rects,
+                                                         1 if rgba8 else 0, out.ctypes.data_as(C.c_void_p)))
+            return
         fn = self._lib.ft_render_enqueue_rgba8 if rgba8 else self._lib.ft_render_enqueue
         self._check(fn(self._ctx, C.byref(camera), res_h, res_v, spp, _capi.dptr(jitter), max_depth, int(seed), rects, n_rects))
 
@@ -298,6 +330,12 @@ class Context(SceneBuilder):
         rgb = np.zeros((o.shape[0], 3))
         self._check(self._lib.ft_debug_colour(self._ctx, _capi.dptr(o), _capi.dptr(d), o.shape[0], max_depth, _capi.dptr(rgb)))
         return rgb
+
+    def devices(self):
+        """The device ordinals behind this context (several for a multi-device context)."""
+        out = (C.c_int32 * 64)()
+        n = self._check(self._lib.ft_debug_devices(self._ctx, out, 64))
+        return list(out[:n])
 
     def commit_times(self):
         """ft_get_commit_times of the last commit: host flatten, device BVH builds, uploads (ms) and the tallest device-built tree."""

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -29,9 +31,39 @@ enum { kStageOther = 0, kStageClosest = 1, kStageShade = 2, kStageResolve = 3, k
 // What a frame copies back when it retires: FrameCounters from `stats` to its end.
 static_assert(sizeof(ftk::FrameCounters) % 16 == 0 && offsetof(ftk::RenderCounters, ref_equiv) == 32, "the hand-over at the end of a frame copies words and clears 16 bytes at a time");
 
+// One host thread per extra device of a multi-device context, alive as long as the context: every frame hands each of them its share
+// (round 2 created and joined a std::thread per device per frame - the same order of time as a device's share of a 4K frame).
+struct DeviceWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, quit = false;
+    void start() {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                std::function<void()> fn = std::move(job);
+                has_job = false;
+                lk.unlock();
+                fn();
+                lk.lock();
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<void()> fn) { std::lock_guard<std::mutex> lk(m); job = std::move(fn); has_job = true; done = false; cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return done; }); }
+    void stop() { { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); } if (th.joinable()) th.join(); }
+};
+
 constexpr int64_t kDeviceBvhMinTris = 4096;   // "bvh_builder" = 2: smaller meshes get the host's swept SAH tree (a few ms at most), larger ones the device's binned one
 struct ft_context {
     std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
+    std::vector<DeviceWorker*> workers;  // ... and one host thread per peer
     bool host_only = false;
     int device = -1;
     int n_cu = 0;
@@ -267,6 +299,9 @@ int32_t ft_create(const int32_t* device_ids, int32_t n_devices, ft_context** out
         rc = create_single(device_ids[k], count, &p);
         if (rc != FT_OK) { ft_destroy(c); return rc; }
         c->peers.push_back(p);
+        DeviceWorker* w = new DeviceWorker();
+        w->start();
+        c->workers.push_back(w);
     }
     *out = c;
     return FT_OK;
@@ -282,6 +317,8 @@ int32_t ft_create_host_only(ft_context** out) {
 
 void ft_destroy(ft_context* c) {
     if (!c) return;
+    for (DeviceWorker* w : c->workers) { w->stop(); delete w; }
+    c->workers.clear();
     for (ft_context* p : c->peers) ft_destroy(p);
     c->peers.clear();
     if (!c->host_only) {
@@ -548,30 +585,63 @@ static int32_t upload_scene(ft_context* c) {
 // The device keeps the last frame in FRAME layout (row 0 = top, Image.fs:39) whatever the tiles were: d_out as FP64 RGB or d_out8 as
 // Image.write's RGBA8 bytes (Image.fs:36).  Fetching copies the rendered rects - whole rows as one copy, narrower rects as a 2D copy -
 // straight into the caller's frame; nothing is gathered or scattered on the host.
+static int32_t copy_frame_out(ft_context* c, void* out, int format, hipStream_t async);
 static int32_t fetch_single(ft_context* c, void* out, int format) {
     if (c->last_n_pix <= 0) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
     if (format != c->last_format) { c->err = format == 1 ? "the last frame was rendered as FP64 RGB (ft_render): no RGBA8 frame to fetch" : "the last frame was rendered as RGBA8 (ft_render_rgba8): no FP64 frame to fetch"; return FT_ERR_STATE; }
     FT_HIP(c, hipSetDevice(c->device));
     FT_HIP(c, hipStreamSynchronize(c->stream));                     // frames queued with ft_render_enqueue may still be running (the streams are non-blocking)
     FT_HIP(c, hipStreamSynchronize(c->tail));                       // ... their k_resolve on its own stream
+    return copy_frame_out(c, out, format, nullptr);
+}
+// The rects of the context's pixel list out of d_out / d_out8 into the caller's frame: blocking copies, or (async != null) queued on that
+// stream behind the frame's k_resolve - the caller's memory should then be page-locked (ft_host_alloc), or the runtime stages the copy.
+static int32_t copy_frame_out(ft_context* c, void* out, int format, hipStream_t async) {
+    auto copy1 = [&](void* d, const void* s_, size_t n) { return async ? hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToHost, async) : hipMemcpy(d, s_, n, hipMemcpyDeviceToHost); };
+    auto copy2 = [&](void* d, size_t dp, const void* s_, size_t sp, size_t w, size_t h) { return async ? hipMemcpy2DAsync(d, dp, s_, sp, w, h, hipMemcpyDeviceToHost, async) : hipMemcpy2D(d, dp, s_, sp, w, h, hipMemcpyDeviceToHost); };
     const size_t px = format == 1 ? 4 : 24, pitch = (size_t)c->last_res_h * px;
     const char* src = static_cast<const char*>(format == 1 ? c->d_out8.p : c->d_out.p);
     char* dst = static_cast<char*>(out);
-    for (size_t k = 0; k < c->pixel_rects.size();) {
+    // A device of a multi-device context holds every N-th 8-row band of the frame: whole rows, equally high, equally spaced.  Those go
+    // out as ONE two-dimensional copy whose "rows" are the bands (band = 8 x pitch contiguous bytes, 8 N x pitch apart on both sides) -
+    // 34 blocking copies of 737 KB per device at 4K otherwise.  A shorter last band follows on its own.
+    size_t k0 = 0;
+    {
+        const auto& R = c->pixel_rects;
+        size_t run = 0;
+        if (R.size() >= 3 && R[0].x0 == 0 && R[0].w == c->last_res_h) {
+            const int step = R[1].y0 - R[0].y0;
+            run = 1;
+            while (run < R.size() && R[run].x0 == 0 && R[run].w == R[0].w && R[run].h == R[0].h && R[run].y0 == R[0].y0 + (int)run * step) ++run;
+            if (step > R[0].h && run >= 3) {
+                const size_t off = (size_t)R[0].y0 * pitch;
+                FT_HIP(c, copy2(dst + off, (size_t)step * pitch, src + off, (size_t)step * pitch, (size_t)R[0].h * pitch, run));
+                k0 = run;
+            }
+        }
+    }
+    for (size_t k = k0; k < c->pixel_rects.size();) {
         const ft_rect r = c->pixel_rects[k];
         if (r.x0 == 0 && r.w == c->last_res_h) {                    // whole rows; vertically adjacent rects go out as one copy
             int rows = r.h;
             size_t k2 = k + 1;
             while (k2 < c->pixel_rects.size() && c->pixel_rects[k2].x0 == 0 && c->pixel_rects[k2].w == r.w && c->pixel_rects[k2].y0 == r.y0 + rows) { rows += c->pixel_rects[k2].h; ++k2; }
-            FT_HIP(c, hipMemcpy(dst + (size_t)r.y0 * pitch, src + (size_t)r.y0 * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost));
+            FT_HIP(c, copy1(dst + (size_t)r.y0 * pitch, src + (size_t)r.y0 * pitch, (size_t)rows * pitch));
             k = k2;
         } else {
             const size_t off = (size_t)r.y0 * pitch + (size_t)r.x0 * px;
-            FT_HIP(c, hipMemcpy2D(dst + off, pitch, src + off, pitch, (size_t)r.w * px, (size_t)r.h, hipMemcpyDeviceToHost));
+            FT_HIP(c, copy2(dst + off, pitch, src + off, pitch, (size_t)r.w * px, (size_t)r.h));
             ++k;
         }
     }
     return FT_OK;
+}
+
+// fn(d) for every listed device d of the context: device 0 on the calling thread, the others on their workers, all at once.
+static void on_every_device(ft_context* c, const std::vector<bool>& take, const std::function<void(size_t)>& fn) {
+    for (size_t d = 1; d < take.size(); ++d) if (take[d]) c->workers[d - 1]->post([&fn, d] { fn(d); });
+    if (take[0]) fn(0);
+    for (size_t d = 1; d < take.size(); ++d) if (take[d]) c->workers[d - 1]->wait();
 }
 
 static int32_t fetch_all(ft_context* c, void* out, int format) {
@@ -583,11 +653,11 @@ static int32_t fetch_all(ft_context* c, void* out, int format) {
     for (ft_context* d : devs) if (d->last_n_pix > 0) with.push_back(d);
     if (with.empty()) { c->err = "no frame rendered yet"; return FT_ERR_STATE; }
     if (with.size() == 1) { const int32_t rc = fetch_single(with[0], out, format); if (rc != FT_OK && with[0] != c) c->err = with[0]->err; return rc; }
-    std::vector<int32_t> rcs(with.size(), FT_OK);                   // every device copies its own bands into the caller's frame, all at once
-    std::vector<std::thread> threads;
-    for (size_t d = 0; d < with.size(); ++d) threads.emplace_back([&, d] { rcs[d] = fetch_single(with[d], out, format); });
-    for (auto& t : threads) t.join();
-    for (size_t d = 0; d < with.size(); ++d) if (rcs[d] != FT_OK) { if (with[d] != c) c->err = with[d]->err; return rcs[d]; }
+    std::vector<int32_t> rcs(devs.size(), FT_OK);                   // every device copies its own bands into the caller's frame, all at once
+    std::vector<bool> take(devs.size());
+    for (size_t d = 0; d < devs.size(); ++d) take[d] = devs[d]->last_n_pix > 0;
+    on_every_device(c, take, [&](size_t d) { rcs[d] = fetch_single(devs[d], out, format); });
+    for (size_t d = 0; d < devs.size(); ++d) if (rcs[d] != FT_OK) { if (devs[d] != c) c->err = devs[d]->err; return rcs[d]; }
     return FT_OK;
 }
 int32_t ft_fetch_frame(ft_context* c, double* out_rgb) { return fetch_all(c, out_rgb, 0); }
@@ -687,16 +757,13 @@ static int32_t render_frame(ft_context* c, const RenderRequest& q, void* out, ft
     std::vector<ft_stats> sts(devs.size());
     // One host thread per device: each queues its bands' frame on its own stream, waits for it and copies its bands straight into the
     // caller's frame (whole rows: one contiguous copy per band).  No device waits for another; the bands meet in `out`.
-    std::vector<std::thread> threads;
-    for (size_t d = 0; d < devs.size(); ++d)
-        threads.emplace_back([&, d] {
-            std::memset(&sts[d], 0, sizeof(ft_stats));
-            if (share[d].empty()) { devs[d]->last_n_pix = 0; return; }
-            RenderRequest qd = q;
-            qd.tiles = share[d].data(); qd.n_tiles = (int32_t)share[d].size();
-            rcs[d] = render_single(devs[d], qd, out, &sts[d], defer);
-        });
-    for (auto& t : threads) t.join();
+    on_every_device(c, std::vector<bool>(devs.size(), true), [&](size_t d) {
+        std::memset(&sts[d], 0, sizeof(ft_stats));
+        if (share[d].empty()) { devs[d]->last_n_pix = 0; return; }
+        RenderRequest qd = q;
+        qd.tiles = share[d].data(); qd.n_tiles = (int32_t)share[d].size();
+        rcs[d] = render_single(devs[d], qd, out, &sts[d], defer);
+    });
     for (size_t d = 0; d < devs.size(); ++d) if (rcs[d] != FT_OK) { if (d) c->err = devs[d]->err; return rcs[d]; }
     if (stats && !defer) {
         std::memset(stats, 0, sizeof *stats);
@@ -1016,7 +1083,14 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         ++n_launches;
     }
     if (!c->fc_clean[turn]) { ftk::launch_report(Lg, fc, F.d_report); c->fc_clean[turn] = true; }   // corner frames end in k_resolve_corner: the hand-over is a launch of its own
-    if (aside) { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->tail); }                  // the frame ends where its last k_resolve does
+    c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v; c->last_format = q.format;
+    if (defer && out) {                                            // ft_render_enqueue_into: the frame's way out is queued behind its last kernel
+        const hipStream_t cs = aside ? c->tail : c->stream;
+        int32_t crc = copy_frame_out(c, out, q.format, cs);
+        if (crc != FT_OK) return crc;
+        boundary_fresh = false;
+    }
+    if (aside) { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->tail); }                  // the frame ends where its last k_resolve (and copy) does
     else if (boundary_fresh) ev1 = boundary;
     else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
     FT_HIP(c, hipGetLastError());
@@ -1122,6 +1196,15 @@ int32_t ft_render_enqueue(ft_context* c, const ft_camera* cam, int32_t res_h, in
 int32_t ft_render_enqueue_rgba8(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                                 int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles) {
     return enqueue(c, RenderRequest{cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, 1});
+}
+/* A queued frame that also leaves the device: the copy into host_out (res_v x res_h x 3 doubles, or x 4 bytes with rgba8 != 0) is queued
+ * behind the frame's last kernel and is complete when ft_render_wait returns (or when a later call retires the frame).  host_out should
+ * come from ft_host_alloc: the copy is then one DMA beside the next frame's tracing - a stream of RGBA8 frames reaches the host at the
+ * rate the device renders them. */
+int32_t ft_render_enqueue_into(ft_context* c, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                               int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, int32_t rgba8, void* host_out) {
+    if (!c || !host_out) return FT_ERR_INVALID;
+    return render_frame(c, RenderRequest{cam, res_h, res_v, spp, jitter_xy, max_depth, seed, tiles, n_tiles, rgba8 ? 1 : 0}, host_out, nullptr, true);
 }
 int32_t ft_render_wait(ft_context* c, ft_stats* stats) {
     if (!c) return FT_ERR_INVALID;
@@ -1301,6 +1384,16 @@ int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9
     if (!a.empty()) std::memcpy(above, a.data(), a.size() * 8);
     if (!b.empty()) std::memcpy(below, b.data(), b.size() * 8);
     return FT_OK;
+}
+
+int32_t ft_debug_devices(ft_context* c, int32_t* ordinals, int32_t capacity) {   // the device ordinals behind a context, in order; returns how many
+    if (!c || capacity < 0 || (capacity > 0 && !ordinals)) return FT_ERR_INVALID;
+    if (c->host_only) return 0;
+    int32_t n = 0;
+    if (n < capacity) ordinals[n] = c->device;
+    ++n;
+    for (ft_context* p : c->peers) { if (n < capacity) ordinals[n] = p->device; ++n; }
+    return n;
 }
 
 int32_t ft_quantise_rgba8(const double* rgb, int64_t n_pixels, uint8_t* out) {   // Image.fs:36, Math.fs:12-16

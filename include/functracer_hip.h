@@ -221,6 +221,12 @@ int32_t ft_fetch_frame_rgba8(ft_context* ctx, uint8_t* out_rgba);
 void* ft_host_alloc(size_t bytes);
 void  ft_host_free(void* p);
 
+/* A queued frame that also leaves the device: the copy into host_out (res_v x res_h x 3 doubles, or x 4 bytes with rgba8 != 0) is queued
+ * behind the frame's last kernel and is complete when ft_render_wait returns (or when a later call retires the frame).  host_out should
+ * come from ft_host_alloc (one DMA beside the next frame's tracing); one buffer per frame in flight (two at most). */
+int32_t ft_render_enqueue_into(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
+                               int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, int32_t rgba8, void* host_out);
+
 /* Pipelined rendering, for hosts that render frame after frame (an animation, a progressive preview):
  * ft_render_enqueue queues a frame exactly as ft_render(out_rgb = NULL) would and returns without waiting, so the host prepares
  * the next frame while this one runs; at most two frames are in flight (queuing a third first waits for the oldest).  On a context
@@ -261,6 +267,9 @@ int32_t ft_debug_slice(const double p0[3], const double n[3], const double tri[9
  * bounces (one k_bounce per level; one bracket around them all, or with "timing" = 2 one per level), 3 resolve and 0 the rest (the
  * fill, classification) with "timing" = 2; otherwise 0 = everything that is not bracketed and 3 = 0.  Index 1 is unused. */
 int32_t ft_get_kernel_times(ft_context* ctx, double ms[5], int32_t launches[5]);
+
+/* The device ordinals behind a context, in the order given to ft_create (at most `capacity` written); returns how many there are. */
+int32_t ft_debug_devices(ft_context* ctx, int32_t* ordinals, int32_t capacity);
 
 /* Image.write's toByte (Image.fs:36): clamp to [0,1], *255, truncate; alpha = 255. */
 int32_t ft_quantise_rgba8(const double* rgb, int64_t n_pixels, uint8_t* out_rgba);

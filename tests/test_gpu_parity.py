@@ -414,6 +414,7 @@ def test_multi_device_context_equals_single_device(hip):
     p = _load("night-house")
     p.lower(hip)
     multi = ft.Context(device=ordinals)
+    assert multi.devices() == ordinals and (n_dev == 1 or len(set(multi.devices())) == len(ordinals))   # distinct GPUs whenever there are several
     p.lower(multi)
     jit = ft.jitter_pattern(2)
     want, st1 = hip.render(p.camera, 320, 180, 2, jit, seed=3)
@@ -438,6 +439,12 @@ def test_multi_device_context_equals_single_device(hip):
     assert np.array_equal(multi.fetch_frame_rgba8(np.zeros((180, 320, 4), dtype=np.uint8)), ft.quantise_rgba8(want))
     u8, _ = multi.render_rgba8(p.camera, 320, 180, 2, jit, seed=3)
     assert np.array_equal(u8, ft.quantise_rgba8(want))
+    with ft.PinnedArray(want.shape) as pinned:                      # ft_host_alloc: the bands of every device as one strided copy each, into page-locked memory
+        pinned[:] = -3.0
+        multi.render(p.camera, 320, 180, 2, jit, seed=3, out=pinned)
+        assert np.array_equal(pinned, want)
+    tall = multi.render(p.camera, 320, 188, 2, jit, seed=3)[0]      # a frame whose last band is four rows high: the strided copy stops in front of it
+    assert np.array_equal(tall, hip.render(p.camera, 320, 188, 2, jit, seed=3)[0])
     multi.close()
 
 
@@ -924,6 +931,23 @@ def test_pipelined_frames_equal_blocking_frames(hip):
     for key in ("rays_traced", "rays_shadow", "rays_reflect", "hits_primary", "rays_reference_equivalent"):
         assert st[key] == blocking[2][1][key], key
     assert hip.kernel_times()["closest"]["launches"] == 3 * per_frame_launches
+    # ft_render_enqueue_into: every queued frame's copy to the host queued behind it, into page-locked memory, FP64 and RGBA8, two in flight
+    with ft.PinnedArray((2, 96, 160, 3)) as f64, ft.PinnedArray((2, 96, 160, 4), dtype=np.uint8) as u8:
+        f64[:] = -1.0
+        u8[:] = 7
+        for k in range(4):
+            hip.render_enqueue(cams[k], 160, 96, 2, jit, out=f64[k & 1])
+            if k >= 1:
+                pass                                               # (slot k & 1 is free again once frame k - 2 was retired by the enqueue of frame k)
+            if k == 1:
+                hip.wait()
+                assert np.array_equal(f64[0], blocking[0][0]) and np.array_equal(f64[1], blocking[1][0])
+        hip.wait()
+        assert np.array_equal(f64[0], blocking[2][0]) and np.array_equal(f64[1], blocking[3][0])
+        for k in range(2):
+            hip.render_enqueue(cams[k], 160, 96, 2, jit, rgba8=True, out=u8[k])
+        hip.wait()
+        assert np.array_equal(u8[0], ft.quantise_rgba8(blocking[0][0])) and np.array_equal(u8[1], ft.quantise_rgba8(blocking[1][0]))
     hip.render_enqueue(cams[3], 160, 96, 2, jit)                  # a blocking call retires what is in flight first
     img, st2 = hip.render(cams[0], 160, 96, 2, jit)
     assert np.array_equal(img, blocking[0][0]) and st2["rays_traced"] == blocking[0][1]["rays_traced"]

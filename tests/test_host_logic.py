@@ -191,9 +191,15 @@ def test_fsharp_binding_matches_the_header():
     doc = open(os.path.join(H.ROOT, "INTEGRATION.md")).read()
     fs = "\n".join(re.findall(r"```fsharp\n(.*?)```", doc, flags=re.S))
     imports = {}
-    for m in re.finditer(r"\[<DllImport\(Lib\)>\]\s*extern\s+\w+\s+(ft_[a-z0-9_]+)\s*\(([^)]*)\)", fs, flags=re.S):
-        args = m.group(2).strip()
-        imports[m.group(1)] = 0 if args == "" else len(args.split(","))
+    aliases = {}                                              # a second binding of an entry point under another F# name (EntryPoint = "...")
+    for m in re.finditer(r"\[<DllImport\(Lib(?:,\s*EntryPoint\s*=\s*\"(ft_[a-z0-9_]+)\")?\)>\]\s*extern\s+\w+\s+(ft_[a-z0-9_]+)\s*\(([^)]*)\)", fs, flags=re.S):
+        args = m.group(3).strip()
+        n_args = 0 if args == "" else len(args.split(","))
+        if m.group(1):
+            aliases[m.group(2)] = m.group(1)
+            assert protos[m.group(1)] == n_args, f"{m.group(2)} -> {m.group(1)}: {n_args} arguments in the F# binding, {protos[m.group(1)]} in the header"
+        else:
+            imports[m.group(2)] = n_args
     assert len(imports) >= 30
     for name, n in imports.items():
         assert name in protos, f"{name} is not declared in functracer_hip.h"
@@ -201,7 +207,7 @@ def test_fsharp_binding_matches_the_header():
     test_hooks = {n for n in protos if n.startswith("ft_debug_")} | {"ft_create_host_only"}
     assert set(protos) - test_hooks <= set(imports), sorted(set(protos) - test_hooks - set(imports))
     for used in re.findall(r"\b(ft_[a-z0-9_]+)\s*\(", re.sub(r"\[<DllImport.*", "", fs)):     # every call in the shim's code is bound
-        assert used in imports, used
+        assert used in imports or used in aliases, used
     # the pieces the round-1 shim lacked: the Transform lowering, Focus, soft-light units
     assert "let rec toFt (t: Transform)" in fs and "Composed ts -> List.collect toFt ts" in fs
     assert "cam.focus with" in fs and "f.apetureAngularSize" in fs
