@@ -78,13 +78,13 @@ struct ft_context {
                                     // binned surface-area tree over the Morton order, 2 = by size: the host's below kDeviceBvhMinTris triangles, 3's from there on
     double commit_ms[4] = {0, 0, 0, 0};   // last ft_scene_commit: flatten on the host, device BVH builds, uploads + the rest, BVH height (not a time)
 
-    int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows k_shade on many-light scenes
+    int64_t chunk_samples = 16ll << 20;   // measured: 8 Mi costs 10-25 % (more, smaller launches), 32 Mi slows the shading on many-light scenes
     int wave_samples_log2 = -1;     // bounce-0 wavefronts take 2^this samples of 64 / 2^this pixels when the sample count allows (option wave_samples); -1: the default, 16
     bool coherent_waves = true;     // diagnostic: 0 routes every wavefront through the incoherent paths
-    int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every k_closest / k_shade, 2 around every stage
+    int timing = 1;                 // HIP events: 0 around the frame only, 1 + around every tracing kernel (k_primary, the k_bounce levels), 2 around every stage
     bool classify_pixels = true;    // k_classify: pixel blocks that cannot see any item are finished before any ray is generated
     int64_t follow_below = -1;      // option "follow_below": a level of the reflection tree in which the previous frame had no more rays than this gets no launch of
-                                    // its own: the last level launched follows them in registers.  -1: two rays per SIMD (8192 on 256 CUs).  Measured at 1080p
+                                    // its own: the last level launched follows them in registers.  -1: two rays per SIMD (2048 on 256 CUs: 8 x n_cu).  Measured at 1080p
                                     // (0 -> 10 000): hollow-sphere x1 0.881 -> 0.863 ms, sample-det x16 1.190 -> 1.164, sample-soft x4 0.905 -> 0.855; following
                                     // levels of 50 000 rays and more loses (hollow-sphere x1 0.976): a lane then drags its wave through every level
     bool level_hint = true;         // launch only as many k_bounce levels as the previous frame of the same signature had (+ 1); 0: always max_depth
@@ -954,7 +954,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     auto& spans = F.spans;
     using Span = ft_context::FrameSlot::Span;
     // HIP events between stages.  An event between two dependent kernels costs about 6 us of stream time, so by default ("timing"
-    // = 1) only the kernels that trace rays (k_primary, k_closest, k_shade, k_tail) are bracketed; 2 brackets every stage, 0 only the frame.
+    // = 1) only the kernels that trace rays (k_primary, the k_bounce levels) are bracketed; 2 brackets every stage, 0 only the frame.
     hipEvent_t ev0 = next_event(F), ev1 = nullptr;
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     hipEvent_t boundary = ev0;
@@ -1147,8 +1147,7 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
         stats->rays_shadow_primary = hrc.rays_shadow_primary; stats->rays_reflect_primary = hrc.rays_reflect_primary;
         stats->kernel_ms = total; stats->trace_kernel_ms = traced;
         {   // Bytes the pipeline has to move by construction of its data layout (ft_device.h).  P generated primaries, Rp / R
-            // reflection rays spawned by k_primary / in all, H hits of the staged bounces; k_tail's rays and hits never become records:
-            // Ti rays were handed to it (written once, read once), Tr spawned and Th shaded inside it.
+            // reflection rays spawned by k_primary / in all, Hb hits shaded by the k_bounce levels.
             const uint64_t P = stats->rays_primary - std::min<uint64_t>(stats->rays_primary, stats->rays_primary_culled);
             const uint64_t RR = hrc.rays_reflect, Rp = hrc.rays_reflect_primary;
             const uint64_t Hb = hrc.hits_total - std::min(hrc.hits_total, hrc.hits_primary);     // hits shaded by k_bounce

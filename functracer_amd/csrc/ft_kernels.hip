@@ -1150,6 +1150,27 @@ FT_DEV void trace(const Scene& S, const Ray& r, Query<ANY>& q, uint32_t* lds, bo
                     default: take = 0xC3u; flip = 0x3Cu; break;
                 }
                 const uint32_t tag_a = leaf_a | ((HA.flags & LF_LIT) ? ID_LIT : 0u), tag_b = leaf_b | ((HB.flags & LF_LIT) ? ID_LIT : 0u);
+                if (fold) {
+                    // The result goes straight into the query, which only asks for the smallest usable t (ties: the earlier hit of the merged
+                    // sequence) or for any usable t: the walk along the merged sequence is not needed, only every hit's intersection type.
+                    // When hit k of A is reached, A's own flag is (k == 1) and B's flag is the parity of the B hits in front of it - those
+                    // with a strictly smaller t (equal t: A first, Csg.fs:78-79); when hit k of B is reached, B's own flag is (k == 1) and
+                    // A's the parity of the A hits with t <= its own.  Same tables, same Take / Flip, and the four hits enter the query in
+                    // an order (A's, then B's) that agrees with the merged one wherever t ties.
+                    const bool a0 = A.n > 0, a1 = A.n > 1, b0 = Bh.n > 0, b1 = Bh.n > 1;
+                    auto in_b_at = [&](double t) { return (b0 && Bh.t0 < t) != (b1 && Bh.t1 < t); };
+                    auto in_a_at = [&](double t) { return (a0 && A.t0 <= t) != (a1 && A.t1 <= t); };
+                    auto emit = [&](bool has, double t, uint32_t id0, uint32_t index) {
+                        const uint32_t type = (0x53714620u >> (4 * index)) & 0xF;
+                        if ((flip >> type) & 1u) id0 ^= ID_FLIP;
+                        if (has && (((take | flip) >> type) & 1u)) q.hit(t, id0, 0u, (id0 & ID_LIT) != 0);
+                    };
+                    if (__any(a0)) emit(a0, A.t0, tag_a | (A.s0 << ID_SUB_SHIFT), 0u + (in_b_at(A.t0) ? 1u : 0u));
+                    if (__any(a1)) emit(a1, A.t1, tag_a | (A.s1 << ID_SUB_SHIFT), 2u + (in_b_at(A.t1) ? 1u : 0u));
+                    if (__any(b0)) emit(b0, Bh.t0, tag_b | (Bh.s0 << ID_SUB_SHIFT), 4u + (in_a_at(Bh.t0) ? 2u : 0u));
+                    if (__any(b1)) emit(b1, Bh.t1, tag_b | (Bh.s1 << ID_SUB_SHIFT), 5u + (in_a_at(Bh.t1) ? 2u : 0u));
+                    break;
+                }
                 int ia = 0, ib = 0;
                 bool in_a = false, in_b = false;
 #pragma unroll
@@ -1371,6 +1392,12 @@ struct JitterFrame {
         i = normalise(V3{g.y * nv.z - g.z * nv.y, nv.x * g.z - nv.z * g.x, g.x * nv.y - g.y * nv.x});          // generator .** normalised
         j = V3{i.y * nv.z - i.z * nv.y, nv.x * i.z - nv.z * i.x, i.x * nv.y - i.y * nv.x};                     // i .** normalised
     }
+    // A frame around a wave-uniform vector (a light's direction) is wave-uniform: into scalar registers with it (uniform_f64) - nine
+    // doubles that otherwise sit in vector registers across every shadow trace of the light's samples.
+    FT_DEV void make_uniform() {
+        nv = {uniform_f64(nv.x), uniform_f64(nv.y), uniform_f64(nv.z)}; i = {uniform_f64(i.x), uniform_f64(i.y), uniform_f64(i.z)};
+        j = {uniform_f64(j.x), uniform_f64(j.y), uniform_f64(j.z)}; m = uniform_f64(m);
+    }
     FT_DEV V3 jittered(Rng& rng) const {
         double x, y;
         for (;;) { x = 2.0 * rng.next() - 1.0; y = 2.0 * rng.next() - 1.0; if ((x * x + y * y) > 1.0) continue; break; }   // Jitter.circle (Jitter.fs:15-21)
@@ -1467,7 +1494,7 @@ FT_DEV void light_visibility(const Scene& S, const Surface& sf, bool lit, unsign
         bool overflow = false;
         if (SOFT && kind == LT_SOFT) {                         // softShadowLightIntensity (Shading.fs:24-31)
             const int samples = reinterpret_cast<cip>(lp + 10)[1];
-            const JitterFrame frame(V3{-lp[0], -lp[1], -lp[2]}, lp[11]);
+            const JitterFrame frame(V3{-lp[0], -lp[1], -lp[2]}, lp[11]);   // (moved into scalar registers - make_uniform - the nine doubles cost MORE scratch: 176 -> 248 B in k_bounce<F,T,T>)
             Rng rng = make_rng(seed_of(), sample, (uint32_t)bounce, (uint32_t)l, 1u);
             for (int k = 0; k < samples; ++k) {                // wave-uniform count; each lane draws its own direction
                 const V3 dj = frame.jittered(rng);
@@ -1755,6 +1782,9 @@ __global__ __launch_bounds__(kBlock, FANCY ? 2 : (!SOFT && !MESH ? FT_BOUNCE_LEA
         }
         double mult = mult0;
         for (int depth = bounce;; ++depth, mult = uniform_f64(mult * lights_f)) {   // one pass, unless this launch follows its rays to the end
+            // (Measured in round 3: keeping the ray in memory across the level's traces - read for the closest hit, read again behind the
+            //  shadow queries, a followed ray parked in the other buffer - frees fourteen registers on paper and changes the scratch of the
+            //  variants by -20 .. +20 bytes either way: the spills come from inside the item evaluation, not from what lives around it.)
             // ---- closest hit; the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
             const Ray ro{r.ox + 0.0001 * r.dx, r.oy + 0.0001 * r.dy, r.oz + 0.0001 * r.dz, r.dx, r.dy, r.dz};   // slightOffset (Shading.fs:129)
             Query<false> q;
@@ -2078,6 +2108,13 @@ FT_DEV void hand_over_frame(FrameCounters* fc, FrameReport* report, unsigned lon
     }
     __syncthreads();
     if (!last) return;
+    // The one workgroup that goes on reads what every other workgroup of the frame wrote (the stripes: no-return atomics, performed at the
+    // L2 / memory side) and clears counters other workgroups of THIS launch read at their start.  Invariant: every read a workgroup makes of
+    // `fc` precedes its ticket in program order and its value was consumed (loop bounds, the window) before the ticket was taken, so by the
+    // time the last ticket is out no read of `fc` is outstanding anywhere.  The tickets stay relaxed (a fence per workgroup is an L2
+    // write-back each: 314 us instead of 18); one agent-scope acquire here, in the one workgroup that reads and clears, makes the order
+    // part of the memory model instead of a property of gfx950's in-order return of consumed loads.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     static_assert(sizeof(RenderCounters) == 128 && kStatStripes * 16 == 4 * kBlock, "the stripes are read as 4 x 256 eight-byte cells");
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&fc->stats[0]);
     for (uint32_t k = 0; k < 4; ++k) cells[k * kBlock + t] = src[k * kBlock + t];           // all loads in flight at once
