@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--weak", action="store_true", help="same as --workload weak")
     ap.add_argument("--side-steps", type=int, default=5, help="frames timed for each workload other than the primary one (0 = skip them)")
     ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed frames queued for this long before the W warm-up steps of every workload (clock ramp); 0 = none")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary legs (frames copied to the host): the counter passes of the profile scripts want a known number of frames")
     ap.add_argument("--blocking", action="store_true", help="render the timed frames one synchronous ft_render at a time instead of queuing them")
     args = ap.parse_args()
 
@@ -123,6 +124,9 @@ def main():
     base_res = tuple(args.res) if args.res else tuple(scene.resolution)
     base_spp = args.spp if args.spp else scene.samples
     ctx = ft.Context(device=device)
+    for kv in filter(None, os.environ.get("FT_OPTS", "").split(",")):      # FT_OPTS="zero_fill_skip=0,...": A/B and counter runs
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     scene.lower(ctx)
 
     primary = args.workload
@@ -214,8 +218,9 @@ def main():
     # The boundary as the reference uses it (Program.fs:63-68): one blocking call that hands the frame back in host memory.
     boundary = {}
     n_b = 10
-    pinned = {"f64_pinned": ft.PinnedArray((res_v, res_h, 3)), "rgba8_pinned": ft.PinnedArray((res_v, res_h, 4), dtype=np.uint8)}   # ft_host_alloc: one DMA at link rate
-    for mode in ("f64", "rgba8", "f64_pinned", "rgba8_pinned"):
+    boundary_modes = () if args.no_boundary else ("f64", "rgba8", "f64_pinned", "rgba8_pinned")
+    pinned = {} if args.no_boundary else {"f64_pinned": ft.PinnedArray((res_v, res_h, 3)), "rgba8_pinned": ft.PinnedArray((res_v, res_h, 4), dtype=np.uint8)}   # ft_host_alloc: one DMA at link rate
+    for mode in boundary_modes:
         buf = pinned[mode].array if mode in pinned else (frame if mode == "f64" else np.zeros((res_v, res_h, 4), dtype=np.uint8))
         call = (lambda: ctx.render(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], out=buf)) if mode.startswith("f64") else \
                (lambda: ctx.render_rgba8(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], out=buf))
@@ -230,7 +235,7 @@ def main():
     # ... and as a host that renders frame after frame would use it: frames queued, each with its copy into page-locked memory behind it
     # (ft_render_enqueue_into, two buffers in turn): the copy of frame N travels while frame N + 1 is traced.
     streaming = {}
-    for mode in ("f64", "rgba8"):
+    for mode in (() if args.no_boundary else ("f64", "rgba8")):
         shape, dt = ((2, res_v, res_h, 3), np.float64) if mode == "f64" else ((2, res_v, res_h, 4), np.uint8)
         with ft.PinnedArray(shape, dtype=dt) as ring:
             for k in range(4):
@@ -323,6 +328,9 @@ def main():
             "gather_ms": round(gather_ms, 3),
             "roofline": roof,
             "per_kernel_ms_per_step": {k: round(v / steps, 4) for k, v in k_times.items()},
+            "per_kernel_note": "HIP-event brackets on the main stream; queued frames overlap (the next frame's k_classify and this frame's k_resolve run on side streams beside k_primary), "
+                               "so `other` is what of a frame's own span its tracing kernels do not cover, not time added to the frame period: ms_per_step minus the dominant kernel is that",
+            "frame_period_minus_dominant_kernel_ms": round(ms_per_step - dom_avg_ms * launches_per_step, 4),
             "per_kernel_launches_per_step": {k: round(v / steps, 3) for k, v in k_launch.items()},
             "layout_bytes_per_frame": {k[len("algorithmic_bytes_"):]: int(v) for k, v in st.items() if k.startswith("algorithmic_bytes_")},
             "rays_per_frame": {"traced_all_ranks": int(P["rays_traced_frame"]), "reference_equivalent_all_ranks": int(P["rays_ref_equiv_frame"]),

@@ -355,7 +355,8 @@ def test_thirteen_nested_texture_functions(hip):
     H.assert_hits_match(hip.closest(o, d), orc.closest(o, d), what="13 uv functions")
 
 
-STOCHASTIC = [("night-house", 160, 90, 3), ("sample-soft", 96, 96, 4), ("repeat", 160, 90, 2), ("house", 160, 90, 2)]
+STOCHASTIC = [("night-house", 160, 90, 3), ("sample-soft", 96, 96, 4), ("repeat", 160, 90, 2), ("house", 160, 90, 2),
+              ("sample", 128, 128, 2)]                            # Scenes/sample.scene as written: JPEG sky texture, focus, two soft lights
 
 
 @pytest.mark.parametrize("name,w,h,spp", STOCHASTIC)

@@ -266,10 +266,12 @@ def test_image_loader_formats(tmp_path):                      # harness counterp
     assert np.array_equal(ft.load_image(tmp_path / "rgb.ppm"), rgb)
     (tmp_path / "ascii.ppm").write_text("P3\n# comment\n2 1\n255\n1 2 3  250 251 252\n")
     assert ft.load_image(tmp_path / "ascii.ppm").tolist() == [[[1, 2, 3], [250, 251, 252]]]
-    Image.fromarray(rgb).save(tmp_path / "x.jpg")
+    Image.fromarray(rgb).save(tmp_path / "x.jpg")                                    # baseline JPEG: read since round 3 (test_jpeg_loader_equals_libjpeg)
+    assert np.array_equal(ft.load_image(tmp_path / "x.jpg"), np.asarray(Image.open(tmp_path / "x.jpg").convert("RGB")))
+    Image.fromarray(rgb).save(tmp_path / "p.jpg", progressive=True)
     with pytest.raises(ft.FtError) as e:
-        ft.load_image(tmp_path / "x.jpg")
-    assert "JPEG" in str(e.value)
+        ft.load_image(tmp_path / "p.jpg")
+    assert "JPEG" in str(e.value) and "progressive" in str(e.value)
     bad = bytearray((tmp_path / "rgb.png").read_bytes())
     bad[40] ^= 0xFF                                                                   # corrupt the IDAT body: CRC check refuses it
     (tmp_path / "bad.png").write_bytes(bad)
@@ -303,3 +305,41 @@ def test_image_texture_lookup_follows_the_reference_index_rule():       # Textur
         ru, rv = abs(u - math.floor(u)), abs(v - math.floor(v))          # Texture.repeat
         x, y = math.floor(ru * 4), math.floor(rv * 3)
         assert np.allclose(got, img[y, x] / 255.0, rtol=0, atol=0), (u, v)
+
+
+def test_jpeg_loader_on_the_committed_texture():
+    """host/ImageLoader.cpp reads baseline JPEG (what `Image.Load<Rgb24>` of Scenes/sample.scene:6 needs).  The committed sky texture decodes
+    to the bytes libjpeg produces (hash taken with Pillow agreeing byte for byte, tools/make_texture_jpg.py); the scene as written parses."""
+    import hashlib
+    img = ft.load_image(os.path.join(H.ROOT, "scenes", "textures", "env4_synth.jpg"))
+    assert img.shape == (192, 384, 3) and hashlib.sha256(img.tobytes()).hexdigest() == "eccc8619bb3cdbdfaa3b68f27e3611a3fcf7f02d30885be439dbfaf11ea6468d"
+    p = ft.parse_scene_file(os.path.join(H.ROOT, "scenes", "sample.scene"))
+    assert p.n_objects == 6 and p.n_lights == 2 and p.samples == 1
+
+
+def test_jpeg_loader_equals_libjpeg(tmp_path):
+    """Grey, 4:4:4, 4:2:2 and 4:2:0 files of odd and tiny sizes, two qualities, with and without restart markers, written by Pillow (libjpeg)
+    and read back by it: the loader's integer inverse DCT, triangle upsampling and fixed-point colour conversion give the same bytes."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 100 * np.sin(x / 9.0) * np.cos(y / 7.0), 127 + 90 * np.cos(x / 5.0 + y / 11.0), 127 + 80 * np.sin((x + y) / 13.0)], -1) + rng.normal(size=(h, w, 3)) * 12
+        return np.clip(img, 0, 255).astype(np.uint8)
+    n = 0
+    for h, w in ((64, 64), (37, 53), (16, 16), (1, 1), (9, 130), (100, 17)):
+        for sub in (0, 1, 2):
+            for kw in ({"quality": 95}, {"quality": 40, "restart_marker_blocks": 3}):
+                path = str(tmp_path / f"t_{h}_{w}_{sub}_{kw['quality']}.jpg")
+                Image.fromarray(picture(h, w)).save(path, subsampling=sub, **kw)
+                assert np.array_equal(ft.load_image(path), np.asarray(Image.open(path).convert("RGB"))), path
+                n += 1
+        path = str(tmp_path / f"g_{h}_{w}.jpg")
+        Image.fromarray(picture(h, w)[..., 0]).save(path, quality=80)
+        assert np.array_equal(ft.load_image(path), np.asarray(Image.open(path).convert("RGB"))), path
+    assert n == 36
+    path = str(tmp_path / "progressive.jpg")
+    Image.fromarray(picture(32, 32)).save(path, progressive=True)
+    with pytest.raises(Exception) as e:                         # refused loudly, not mis-decoded
+        ft.load_image(path)
+    assert "progressive" in str(e.value)

@@ -63,10 +63,10 @@ for k in ("k_primary", "k_bounce"):
         row["layout"] = {"bytes_per_frame": int(layout[k]), "GBps": round(g, 1), "frac_of_hbm_peak": round(g / HBM_PEAK_GBPS, 4)}
     t = traffic.get(k)
     if t:
-        # the counter passes render 46 frames; launches counted there / 46 = launches per frame
-        per_frame = t["traffic_bytes_per_launch"] * t["launches"] / 46.0
-        row["hbm_traffic"] = {"bytes_per_frame": int(per_frame), "read": int(t["fetch_corrected_bytes_per_launch"] * t["launches"] / 46.0),
-                              "written": int(t["write_bytes_per_launch"] * t["launches"] / 46.0), "GBps": round(per_frame / sec / 1e9, 1),
+        # the counter passes render 24 frames; launches counted there / 24 = launches per frame
+        per_frame = t["traffic_bytes_per_launch"] * t["launches"] / 24.0
+        row["hbm_traffic"] = {"bytes_per_frame": int(per_frame), "read": int(t["fetch_corrected_bytes_per_launch"] * t["launches"] / 24.0),
+                              "written": int(t["write_bytes_per_launch"] * t["launches"] / 24.0), "GBps": round(per_frame / sec / 1e9, 1),
                               "frac_of_hbm_peak": round(per_frame / sec / 1e9 / HBM_PEAK_GBPS, 4)}
         if layout[k]:
             row["hbm_traffic"]["over_layout"] = round(per_frame / layout[k], 3)
