@@ -69,6 +69,7 @@ def main():
                     help="which workload the K timed steps (and `value`) are: auto = headline at N = 1, config5 (strong) at N > 1")
     ap.add_argument("--strong", action="store_true", help="same as --workload headline: the 1080p x 16 frame strong-scaled")
     ap.add_argument("--weak", action="store_true", help="same as --workload weak")
+    ap.add_argument("--no-alone", action="store_true", help="skip the untimed frames that measure each kernel with the frame pipeline off (roofline.alone); the counter passes use it: a known number of frames")
     ap.add_argument("--side-steps", type=int, default=5, help="frames timed for each workload other than the primary one (0 = skip them)")
     ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed frames queued for this long before the W warm-up steps of every workload (clock ramp); 0 = none")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary legs (frames copied to the host): the counter passes of the profile scripts want a known number of frames")
@@ -206,6 +207,21 @@ def main():
     res_h, res_v = P["res"]
     spp = P["spp"]
 
+    # The same frames with the frame pipeline switched off (every kernel alone on the device, one stream): what a launch of each kernel
+    # takes when nothing runs beside it - the figure a serial rocprofv3 pass shows (profiles/*_serial_kernel_stats.csv).  Not the timed region.
+    alone = {}
+    if world == 1 and not args.no_alone:
+        for k in ("classify_ahead", "resolve_aside"):
+            ctx.set_option(k, 0)
+        for _ in range(2):
+            for _ in range(P["steps"]):
+                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"])
+            ctx.wait()
+            alone = {k: v["ms"] / max(1, v["launches"]) for k, v in ctx.kernel_times().items() if v["launches"]}
+        for k, v in {"classify_ahead": 1, "resolve_aside": 1, **{kv.split("=")[0]: int(kv.split("=")[1]) for kv in filter(None, os.environ.get("FT_OPTS", "").split(","))}}.items():
+            if k in ("classify_ahead", "resolve_aside"):
+                ctx.set_option(k, v)
+
     # The primary workload's frame: this rank's bands D2H, gathered on the host of rank 0 (outside the timed region).
     _, _ = ctx.render(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], fetch=False)
     frame = np.zeros((res_v, res_h, 3))
@@ -280,6 +296,11 @@ def main():
                 "frame_model": {"bytes_per_frame": int(frame_bytes), "GBps": round(frame_bytes / kernel_s / 1e9, 2), "frac": round(frame_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS, 6),
                                 "note": "8(d)'s whole-frame form: (192 x rays_traced + 24 x pixels) / kernel seconds of the frame"},
                 "note": "the path is FP64 vector-ALU / latency bound, not HBM bound (DESIGN.md 5): `real_bound` is the fraction that says how well the kernel uses the chip"}
+        if alone.get(dom):
+            roof["alone"] = {"avg_launch_ms": round(alone[dom], 4), "GBps": round(survey_bytes / (alone[dom] * 1e-3) / 1e9, 2),
+                             "frac": round(survey_bytes / (alone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                             "note": "the same launch with the frame pipeline off (options classify_ahead = resolve_aside = 0; frames after the timed region): in the timed region "
+                                     "the next frame's k_classify and the previous frame's k_resolve share the CUs with this kernel, which lengthens each launch and shortens the frame period"}
         if layout_bytes is not None:
             g = layout_bytes / (dom_avg_ms * 1e-3) / 1e9
             roof["layout_model"] = {"bytes_per_launch": round(layout_bytes), "GBps": round(g, 2), "frac": round(g / HBM_PEAK_GBPS, 6),

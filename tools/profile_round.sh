@@ -5,10 +5,15 @@ set -e
 tag=$1
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --side-steps 0"
-P="$B --prewarm-ms 0 --no-boundary"   # the counter passes: a known number of frames (3 + 20 + 1, all FP64), no clock pre-warm, Colour.Zero written every frame
+P="$B --prewarm-ms 0 --no-boundary --no-alone"   # the counter passes: a known number of frames (3 + 20 + 1, all FP64), no clock pre-warm, Colour.Zero written every frame
 # the two traffic passes run with FT_OPTS=zero_fill_skip=0: k_resolve then writes every pixel every frame and its bytes are known exactly (the FETCH_SIZE calibration rests on them)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B > gpurun_out/${tag}_bench_under_stats.json 2>/dev/null
 cp $(ls gpurun_out/${tag}_stats/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats.csv
+python3 tools/trace_percentiles.py gpurun_out/${tag}_stats > gpurun_out/${tag}_kernel_percentiles.txt     # frames are pipelined: overlapped launches stretch one another (median vs mean)
+# the same command with the frame pipeline off: every kernel alone on the device (what bench.py reports as roofline.alone)
+FT_OPTS=classify_ahead=0,resolve_aside=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_serial -- $B > /dev/null 2>&1
+cp $(ls gpurun_out/${tag}_stats_serial/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_serial_kernel_stats.csv
+python3 tools/trace_percentiles.py gpurun_out/${tag}_stats_serial >> gpurun_out/${tag}_kernel_percentiles.txt
 FT_OPTS=zero_fill_skip=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -- $P > /dev/null 2>&1
 FT_OPTS=zero_fill_skip=0 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d gpurun_out/${tag}_write -- $P > /dev/null 2>&1
 ACTIVE_PIXELS=$(python3 -c "import json,sys; d=json.loads(open('gpurun_out/${tag}_bench_under_stats.json').read().strip().splitlines()[-1]); r=d['rays_per_frame']; print((r['primary_listed_all_ranks'] - r['primary_never_generated_all_ranks']) // 16)")

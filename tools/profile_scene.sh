@@ -7,7 +7,7 @@ tag=$1; scene=$2; spp=$3
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 T=gpurun_out/${tag}_${scene}x${spp}
 B="python3 bench.py --scene $scene --spp $spp --res 1920 1080 --steps 20 --warmup 3 --no-cpu-baseline --side-steps 0"
-P="$B --prewarm-ms 0 --no-boundary"   # the counter passes: a known number of frames (3 + 20 + 1, all FP64), no clock pre-warm, Colour.Zero written every frame
+P="$B --prewarm-ms 0 --no-boundary --no-alone"   # the counter passes: a known number of frames (3 + 20 + 1, all FP64), no clock pre-warm, Colour.Zero written every frame
 # the two traffic passes run with FT_OPTS=zero_fill_skip=0: k_resolve then writes every pixel every frame and its bytes are known exactly (the FETCH_SIZE calibration rests on them)
 rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_stats -- $B > ${T}_bench_under_stats.json 2>/dev/null
 cp $(ls ${T}_stats/*/*kernel_stats.csv | head -1) ${T}_kernel_stats.csv
