@@ -143,6 +143,10 @@ struct ft_context {
     // so the frame is complete however deep it goes.  -1: no history, launch max_depth levels.
     int staged_hint = -1;
     uint64_t staged_signature = 0;
+    int64_t active_hint = -1;        // active pixels of the last classified frame retired (and its signature): how wide the next frame's windows may be
+    uint64_t active_signature = 0;
+    int64_t window_cap = 64ll << 20; // option "window_cap": listed samples a hinted window may span
+    bool window_hint = false;        // option "window_hint": 1 widens a classified frame's windows by what the last frame of its signature left inactive (see render_single)
     uint64_t commit_serial = 0;
     bool csg_auto_grow = true;   // ft_render: double csg_mesh_capacity and render again when a hit list overflows
     bool accum_open = false;        // kernel times are being summed over pipelined frames (reset by the next enqueue after a wait)
@@ -354,6 +358,8 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
         c->wave_samples_log2 = l; for (ft_context* p : c->peers) p->wave_samples_log2 = l; return FT_OK;
     }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
+    if (!std::strcmp(key, "window_cap")) { if (value < 64 || value > (1ll << 30)) return FT_ERR_INVALID; c->window_cap = value; for (ft_context* p : c->peers) p->window_cap = value; return FT_OK; }
+    if (!std::strcmp(key, "window_hint")) { c->window_hint = value != 0; for (ft_context* p : c->peers) p->window_hint = value != 0; return FT_OK; }
     if (!std::strcmp(key, "resolve_aside")) { c->resolve_aside = value != 0; for (ft_context* p : c->peers) p->resolve_aside = value != 0; return FT_OK; }
     if (!std::strcmp(key, "resolve_blocks")) { if (value < 0 || value > 8) return FT_ERR_INVALID; c->resolve_blocks_cap = (int)value; for (ft_context* p : c->peers) p->resolve_blocks_cap = (int)value; return FT_OK; }
     if (!std::strcmp(key, "classify_after_trace")) { c->classify_after_trace = value != 0; for (ft_context* p : c->peers) p->classify_after_trace = value != 0; return FT_OK; }
@@ -577,7 +583,7 @@ static int32_t upload_scene(ft_context* c) {
     c->blocks_bounce = ftk::occupancy_blocks_bounce(lds, c->variant);
     c->blocks_resolve = ftk::occupancy_blocks_resolve();
     c->committed = true;
-    ++c->commit_serial; c->staged_hint = -1;
+    ++c->commit_serial; c->staged_hint = -1; c->active_hint = -1;
     return FT_OK;
 }
 
@@ -865,7 +871,22 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     // of the frame: they are twice as wide (measured at 1080p x 16 in round 1: bunny 0.58 -> 0.55 ms, hollow-sphere 6.1 -> 5.8, sample
     // 1.64 -> 1.50; the unclassified night-house loses 14 % at that width and keeps the narrow one).
     const bool classify = c->classify_pixels && jitter_bounded && !corner && c->pixels_tiled && !cam->has_focus && c->flat.cull_bundle && c->flat.item_pc.size() > 1 && !c->flat.unbounded;
-    const int64_t chunk_budget = classify ? 2 * c->chunk_samples : c->chunk_samples;
+    uint64_t signature = c->commit_serial * 0x9E3779B97F4A7C15ull;
+    for (uint64_t v : {(uint64_t)res_h, (uint64_t)res_v, (uint64_t)spp, (uint64_t)max_depth, (uint64_t)n_pix_total, (uint64_t)c->chunk_samples, (uint64_t)(corner ? 1 : 0)})
+        signature = (signature ^ v) * 0x100000001B3ull;
+    int64_t chunk_budget = classify ? 2 * c->chunk_samples : c->chunk_samples;
+    // The windows of a classified frame are cut from its LISTED pixels (the host does not know the active list's length when it queues
+    // them), so a sparse frame is one window of work and a row of launches that find theirs empty (~20 us each: k_primary + k_resolve +
+    // the counter fill; 3840x2160x64 of the bunny: 16 windows, 14 empty).  Option "window_hint" = 1: when the last frame of this
+    // signature kept one pixel in `widen`, windows up to `widen` times as wide (at most "window_cap" listed samples) still hold no more
+    // ACTIVE samples than the measured optimum.  OFF by default - measured (tools/window_hint_ab.py, tools/window_sweep.py): the empty
+    // launches go (`other` 0.33 -> 0.23 ms on that frame) but k_primary over the SAME active samples runs 0 - 9 % slower behind wider
+    // colour planes, varying from one allocation of the planes to the next (the stride between the planes is not it: padding it changed
+    // nothing): a rank's quarter gains 4 %, a half loses 3 - 7 %, an eighth and the whole frame stay where they were.
+    if (classify && c->window_hint && c->active_hint >= 0 && c->active_signature == signature) {
+        const int64_t widen = std::max<int64_t>(1, std::min<int64_t>(16, n_pix_total / std::max<int64_t>(64, c->active_hint)));
+        chunk_budget = std::max(chunk_budget, std::min(c->window_cap, chunk_budget * widen));
+    }
     int64_t pix_per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_pix_total, chunk_budget / spp));
     if (pix_per_chunk > 64) {
         // equal chunks rather than full ones and a remainder: a short last chunk is all latency (measured on night-house at
@@ -970,9 +991,6 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         if (boundary && b) spans.push_back(Span{boundary, b, kind});
         boundary = b; boundary_fresh = true;
     };
-    uint64_t signature = c->commit_serial * 0x9E3779B97F4A7C15ull;
-    for (uint64_t v : {(uint64_t)res_h, (uint64_t)res_v, (uint64_t)spp, (uint64_t)max_depth, (uint64_t)n_pix_total, (uint64_t)c->chunk_samples, (uint64_t)(corner ? 1 : 0)})
-        signature = (signature ^ v) * 0x100000001B3ull;
     // What decides which blocks k_classify finishes: the scene, the camera, the frame's size and pixel list, the jitter pattern's extent.
     uint64_t zsig = signature;
     {
@@ -1022,7 +1040,10 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     }
     double* const out_rgb = q.format == 1 ? nullptr : c->d_out.as<double>();
     uint8_t* const out_rgba = q.format == 1 ? c->d_out8.as<uint8_t>() : nullptr;
-    const bool aside = defer && c->resolve_aside && !corner && timing < 2;   // queued frames: k_resolve on its own stream (blocking frames have nothing to hide it in)
+    // queued frames: k_resolve on its own stream (blocking frames have nothing to hide it in).  Frames of one chunk only: a frame cut into many
+    // windows (3840x2160x64: 16, most of them empty behind the classification) pays an event pair per window and gains nothing - the windows'
+    // small launches already overlap on one stream (measured: 3.46 -> 3.63 ms with it, profiles/r03_z_overlap_by_scene.json)
+    const bool aside = defer && c->resolve_aside && !corner && timing < 2 && jobs.size() == 1;
     for (const Job& job : jobs) {
         const uint32_t n_pix = job.n_ids;
         const uint32_t n_samples = n_pix * (uint32_t)spp;
@@ -1122,6 +1143,7 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
     const int64_t few = c->follow_below >= 0 ? c->follow_below : 8ll * c->n_cu;   // -1: two rays per SIMD
     while (deepest + 1 <= ftk::kMaxBounce && (int64_t)F.h_report->n_rays[deepest + 1] > few) ++deepest;
     c->staged_hint = deepest; c->staged_signature = F.signature;
+    if (F.classify && !classify_failed) { c->active_hint = (int64_t)F.h_report->n_pix_active; c->active_signature = F.signature; }
     const int timing = F.timing; const int32_t spp = F.spp; const int64_t n_pix_total = F.n_pix_total; const bool classify = F.classify;
     hipEvent_t ev0 = F.ev0, ev1 = F.ev1;
     double bracketed = 0.0, traced = 0.0;
