@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -72,6 +73,7 @@ struct ft_context {
 
     fth::SceneGraph graph;
     fth::FlatScene flat;
+    std::vector<float> cull_items_and_rows;   // what d_cull_items holds (the upload's source)
     bool committed = false;
     int bvh_builder = 2;            // who builds the exact BVH of top-level-Leaf meshes: 0 = the host (swept surface-area split: the best tree, 1.2 ms for 980
                                     // triangles but 160 ms for 69.6 K), 1 = the device's linear BVH (ft_bvh.hip: ~1 ms, traces ~9 % slower), 3 = the device's
@@ -527,7 +529,18 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_bleaves, f.bsp_leaves)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tris, f.tris)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_culls, f.culls)) != FT_OK) return rc;
-    if ((rc = upload(c, c->d_cull_items, f.cull_items)) != FT_OK) return rc;
+    {   // behind the items' float records: a float image of every parallel-sensitive direction (x, y, z, its length rounded up), which lane k of a
+        // coherent wave tests against the bundle's cone before any ray is tested against it exactly (rows_nearly_parallel, ft_kernels.hip)
+        std::vector<float>& v = c->cull_items_and_rows;
+        v = f.cull_items;
+        v.resize(8 * (f.item_pc.size() - 1), 0.0f);
+        for (size_t k = 0; k + 2 < f.cull_rows.size(); k += 3) {
+            const double len = std::sqrt(f.cull_rows[k] * f.cull_rows[k] + f.cull_rows[k + 1] * f.cull_rows[k + 1] + f.cull_rows[k + 2] * f.cull_rows[k + 2]);
+            float lf = (float)len; while ((double)lf < len) lf = std::nextafter(lf, std::numeric_limits<float>::infinity());
+            v.push_back((float)f.cull_rows[k]); v.push_back((float)f.cull_rows[k + 1]); v.push_back((float)f.cull_rows[k + 2]); v.push_back(lf);
+        }
+        if ((rc = upload(c, c->d_cull_items, v)) != FT_OK) return rc;
+    }
     if ((rc = upload(c, c->d_cull_rows, f.cull_rows)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_item_pc, f.item_pc)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_wide, f.wide)) != FT_OK) return rc;

@@ -838,24 +838,54 @@ FT_DEV bool cone_may_reach(float ix, float iy, float iz, float radius, uint32_t 
     const float beyond = h > 0.0f ? w * B.cos_t - h * B.sin_t : fmaxf(w * B.cos_t, -h);
     return !(beyond > reach) || (rows & B.par_rows) != 0u;
 }
-// Lane k tests top-level ITEM k: bit k of the result is clear only when no ray inside the cone can give a usable hit on it.
-FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B) {
+// Lane k tests top-level ITEM k: bit k of the result is clear only when no ray inside the cone can give a usable hit on it.  The records are
+// requested (item_recs) before the cone is worked out - some 150 instructions, two wave reductions - so their way from memory is covered.
+struct ItemRecs { float x[2], y[2], z[2], r[2]; uint32_t rows[2]; };
+FT_DEV ItemRecs item_recs(const Scene& S) {
+    ItemRecs R{{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0u, 0u}};
+    const int n_pass = S.n_items > 64 ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int item = pass * 64 + (int)lane_id();
+        if (item < S.n_items) {
+            const float* I = S.cull_items + 8 * (item + (int)opaque_zero());   // (worked out here: hoisted out of the batch loop, the address was spilled)
+            R.x[pass] = I[0]; R.y[pass] = I[1]; R.z[pass] = I[2]; R.r[pass] = I[3]; R.rows[pass] = __float_as_uint(I[4]);
+        }
+    }
+    return R;
+}
+FT_DEV ItemMask items_in_cone(const Scene& S, const Cone& B, const ItemRecs& R) {
     ItemMask M{~0ull, ~0ull, true};
     const float origin_mag = fabsf(B.cx) + fabsf(B.cy) + fabsf(B.cz);
     const int n_pass = S.n_items > 64 ? 2 : 1;
     for (int pass = 0; pass < n_pass; ++pass) {
         const int item = pass * 64 + (int)lane_id();
         bool keep = true;
-        if (item < S.n_items) {
-            const float* I = S.cull_items + 8 * (item + (int)opaque_zero());   // (worked out here: hoisted out of the batch loop, the address was spilled)
-            const uint32_t rows = __float_as_uint(I[4]);
-            keep = cone_may_reach(I[0], I[1], I[2], I[3], rows, B, origin_mag);
-        }
+        if (item < S.n_items) keep = cone_may_reach(R.x[pass], R.y[pass], R.z[pass], R.r[pass], R.rows[pass], B, origin_mag);
         const unsigned long long km = __ballot(keep && item < S.n_items);
         if (pass == 0) M.lo = km; else M.hi = km;
     }
     if (n_pass == 1) M.hi = 0ull;
     return M;
+}
+// Face directions (Plane.fs:13-16: a ray within 2 kEps of parallel to a plane hits it at its own origin) that some ray of the wave is
+// nearly parallel to: items using one of them are kept whatever the cone says.  Per direction that is an exact FP64 product per lane and a
+// wave vote - forty scalar loads and twenty votes per query on night-house, for a mask that is almost always empty.  So lane k first
+// asks of direction k whether ANY unit vector u within the cone could have |row . u| < 2 kEps / |d| (|d| >= 1e-3 is the caller's
+// condition): |row . u| >= |row . a| cos t - |row| sin t, in floats with the roundings covered; only the directions that cannot be
+// ruled out this way (none, unless the bundle grazes a face) get the exact test.
+FT_DEV uint32_t rows_nearly_parallel(const Scene& S, const Ray& r, bool live, float ax, float ay, float az, float cos_t, float sin_t) {
+    bool cand = false;
+    if ((int)lane_id() < S.n_cull_rows) {
+        const float* Rf = S.cull_items + 8 * S.n_items + 4 * (int)lane_id();
+        cand = !(fabsf(Rf[0] * ax + Rf[1] * ay + Rf[2] * az) * cos_t > Rf[3] * (sin_t + 2e-5f) + 2.2e-4f);
+    }
+    uint32_t todo = (uint32_t)__ballot(cand), par_rows = 0u;
+    while (todo) {
+        const uint32_t k = (uint32_t)__builtin_ctz(todo); todo &= todo - 1u;
+        cdp Rw = S.cull_rows + 3u * k;
+        if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
+    }
+    return par_rows;
 }
 FT_DEV float wave_max(float v) { return -wave_min(-v); }
 // Shadow rays towards a point light (Shading.fs:38-42: d = normalise (position - point), maxDistance = |position - point|): every ray
@@ -866,6 +896,7 @@ FT_DEV ItemMask bundle_cull_to_light(const Scene& S, const Ray& r, bool live, cd
     ItemMask M{~0ull, ~0ull, false};
     const unsigned long long lm = __ballot(live);
     if (lm == 0ull) return M;
+    const ItemRecs recs = item_recs(S);
     float ex = -(float)r.dx, ey = -(float)r.dy, ez = -(float)r.dz;  // from the light towards the ray's origin
     const float l2 = ex * ex + ey * ey + ez * ez;
     const float far_lane = (float)max_dist;
@@ -881,21 +912,18 @@ FT_DEV ItemMask bundle_cull_to_light(const Scene& S, const Ray& r, bool live, cd
     const float cx = (float)light[0], cy = (float)light[1], cz = (float)light[2];
     const float far = wave_max(live ? far_lane : 0.0f);
     const float rho = 1e-5f * (1.0f + fabsf(cx) + fabsf(cy) + fabsf(cz) + far);     // the float images of the light and of the directions
-    uint32_t par_rows = 0;
-    for (int k = 0; k < S.n_cull_rows; ++k) {
-        cdp Rw = S.cull_rows + 3u * (uint32_t)k;
-        if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
-    }
-    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, far * 1.0001f + rho});
+    const uint32_t par_rows = rows_nearly_parallel(S, r, live, ax, ay, az, cos_t, sin_t);   // (|d| is within [0.5, 2] here)
+    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, far * 1.0001f + rho}, recs);
 }
 FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     ItemMask M{~0ull, ~0ull, false};
     if (S.n_items < 3 || S.n_cull_rows < 0) return M;
     const unsigned long long lm = __ballot(live);
     if (lm == 0ull) return M;
+    const ItemRecs recs = item_recs(S);
     float dx = (float)r.dx, dy = (float)r.dy, dz = (float)r.dz;
     const float l2 = dx * dx + dy * dy + dz * dz;
-    if (__any(live && !(l2 > 1e-30f && l2 < 1e30f))) return M;      // zero / huge / NaN directions: no bound
+    if (__any(live && !(l2 > 1e-6f && l2 < 1e30f))) return M;       // tiny / huge / NaN directions: no bound (rows_nearly_parallel counts on |d| >= 1e-3)
     const float inv = __builtin_amdgcn_rsqf(l2);
     dx *= inv; dy *= inv; dz *= inv;
     const float ox = (float)r.ox, oy = (float)r.oy, oz = (float)r.oz;
@@ -913,12 +941,8 @@ FT_DEV ItemMask bundle_cull(const Scene& S, const Ray& r, bool live) {
     const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t)) + 1e-5f;   // sine of the widened half-angle, rounded up
     const float rho = sqrtf(rho2) * 1.0001f;
     // rays of the wave nearly parallel to a face direction: items using that direction are kept (exact FP64 test as in OP_CULL)
-    uint32_t par_rows = 0;
-    for (int k = 0; k < S.n_cull_rows; ++k) {
-        cdp Rw = S.cull_rows + 3u * (uint32_t)k;
-        if (__any(live && fabs(dot3(Rw[0], Rw[1], Rw[2], r.dx, r.dy, r.dz)) < 2.0 * kEps)) par_rows |= 1u << k;
-    }
-    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, __builtin_inff()});
+    const uint32_t par_rows = rows_nearly_parallel(S, r, live, ax, ay, az, cos_t, sin_t);
+    return items_in_cone(S, Cone{ax, ay, az, cx, cy, cz, cos_t, sin_t, rho, par_rows, __builtin_inff()}, recs);
 }
 
 // Exact skip test of one top-level item (cull record C: centre, radius^2, number of face directions, the directions) for one ray.

@@ -7,7 +7,9 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 lib = ft.hip_lib()
 ctx = ft.Context(0)
 buf = (C.c_ulonglong * 48)()
-for name, spp in (("hollow-sphere", 16), ("hollow-sphere", 1), ("night-house-det", 16), ("sample-det", 16), ("bunny", 16)):
+for kv in filter(None, os.environ.get("FT_OPTS", "").split(",")):
+    k_, v_ = kv.split("="); ctx.set_option(k_, int(v_))
+for name, spp in (("hollow-sphere", 16), ("hollow-sphere", 1), ("night-house-det", 16), ("sample-det", 16)):
     p = ft.parse_scene_file(os.path.join(R, "scenes", name + ".scene")); p.lower(ctx)
     jit = ft.jitter_pattern(spp)
     ctx.render(p.camera, 1920, 1080, spp, jit, fetch=False)
