@@ -999,9 +999,11 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
     // by explicit slack, a ray nearly parallel to one of the item's face directions is never turned away), and the exact test - a
     // 192-byte record and ~45 FP64 instructions - only runs for the items some lane's float test could not rule out.  An incoherent
     // wave meets most of a scene's items this way (hollow-sphere: 26 per query, 4 of them needed).
-    const float ox = (float)r.ox, oy = (float)r.oy, oz = (float)r.oz, dx = (float)r.dx, dy = (float)r.dy, dz = (float)r.dz;
+    const float ox = (float)r.ox, oy = (float)r.oy, oz = (float)r.oz;
+    float dx = (float)r.dx, dy = (float)r.dy, dz = (float)r.dz;
     const float dd = dx * dx + dy * dy + dz * dz;
     const bool tame = live && dd > 1e-30f && dd < 1e30f && fabsf(ox) < 1e15f && fabsf(oy) < 1e15f && fabsf(oz) < 1e15f;   // else: no float verdicts for this lane
+    { const float inv = __builtin_amdgcn_rsqf(dd); dx *= inv; dy *= inv; dz *= inv; }   // a unit direction (to a few ulps: the 1e-4 slack below covers it) drops |d|^2 out of every comparison
     uint32_t par_lane = 0;                                         // face directions this lane's ray is nearly parallel to (Plane.fs:13-16)
     const bool rows_known = S.n_cull_rows >= 0;                    // (more than 32 distinct directions in the scene: the table does not exist)
     for (int k = 0; k < S.n_cull_rows; ++k) {
@@ -1011,10 +1013,11 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
     // The float records sit in the lanes (lane j: items j and 64 + j, one vector load each before the loop) and are handed round by
     // v_readlane: fetched one by one through scalar loads, every item of the loop began with a memory round trip of its own - the
     // fixed ~17 us a batch of incoherent rays cost whatever it held was mostly this loop, twice (closest, then shadow).
-    struct ItemRec { float x, y, z, r, rows; };
+    struct ItemRec { float x, y, z, r2, rows; };                  // r2: the bounding sphere's radius squared, inflated (+inf: unbounded - no comparison below holds)
     auto load_rec = [&](int item) {
         const float* I = S.cull_items + 8 * ((item < n ? item : 0) + (int)opaque_zero());
-        return ItemRec{I[0], I[1], I[2], I[3], I[4]};
+        const float rad = I[3];
+        return ItemRec{I[0], I[1], I[2], rad < 1e30f ? rad * rad * 1.001f : __builtin_inff(), I[4]};
     };
     const ItemRec lo = load_rec((int)lane_id());
     ItemRec hi{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1024,17 +1027,21 @@ FT_DEV ItemMask exact_cull(const Scene& S, const Ray& r, bool live) {
         const int src = k & 63;
         const bool first = k < 64;                                  // wave-uniform
         const float I[5] = {lane_of(first ? lo.x : hi.x, src), lane_of(first ? lo.y : hi.y, src), lane_of(first ? lo.z : hi.z, src),
-                            lane_of(first ? lo.r : hi.r, src), lane_of(first ? lo.rows : hi.rows, src)};
-        const float cx = ox - I[0], cy = oy - I[1], cz = oz - I[2], rad = I[3];
+                            lane_of(first ? lo.r2 : hi.r2, src), lane_of(first ? lo.rows : hi.rows, src)};
+        const float cx = ox - I[0], cy = oy - I[1], cz = oz - I[2];
         const uint32_t rows = __float_as_uint(I[4]);
-        const float b = cx * dx + cy * dy + cz * dz, cc = cx * cx + cy * cy + cz * cz, r2 = rad * rad * 1.001f;
-        const float slack = 1e-4f * (cc * dd) + 1e-30f;
-        const bool line_misses = (cc * dd - b * b) > r2 * dd + slack;              // the line passes the (inflated) bounding sphere by a margin
-        const bool leaves = cc > r2 + 1e-4f * cc && b > 0.0f && b * b > 1e-6f * (cc * dd);   // outside it and moving away: every hit has t < 0
-        const bool certainly_missed = tame && rows_known && (line_misses || leaves) && (rows & par_lane) == 0u && rad < 1e30f;
+        const float b = cx * dx + cy * dy + cz * dz, cc = cx * cx + cy * cy + cz * cz, b2 = b * b;
+        const float margin = cc * 0.9999f - I[3];                   // |c|^2 less the slack for every rounding above, less the inflated radius^2
+        const bool line_misses = margin > b2;                       // the line passes the bounding sphere by a margin: |c|^2 - (c.u)^2 > r^2 + slack
+        const bool leaves = margin > 0.0f && b > 0.0f && b2 > 1e-6f * cc;   // outside it and moving away: every hit has t < 0
+        const bool certainly_missed = tame && rows_known && (line_misses || leaves) && (rows & par_lane) == 0u;
         if (!__any(live && !certainly_missed)) continue;
-        const bool need = live && !item_missed(S, (uint32_t)k, r);
-        if (__any(need)) { if (k < 64) M.lo |= 1ull << k; else M.hi |= 1ull << (k - 64); }
+        // What the float test could not rule out is kept as it is: the mask only has to hold every item some lane can hit, and the FP64
+        // image of the same test (item_missed: a 192-byte record through scalar loads, one exposed round trip per surviving item - 14 K
+        // of the 21 K cycles this function took per query on hollow-sphere) turned away almost nothing the float test had let through.
+        // Only a scene without the direction table (more than 32 distinct face directions) still needs it: there the float test says nothing.
+        if (!rows_known && !__any(live && !item_missed(S, (uint32_t)k, r))) continue;
+        if (k < 64) M.lo |= 1ull << k; else M.hi |= 1ull << (k - 64);
     }
     M.valid = true;
     return M;
