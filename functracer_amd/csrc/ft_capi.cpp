@@ -128,7 +128,7 @@ struct ft_context {
         struct Span { hipEvent_t a, b; int kind; };
         std::vector<Span> spans;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
-        hipEvent_t traced = nullptr;            // behind the frame's last tracing kernel, in front of its k_resolve: where the NEXT frame's k_classify may start
+        hipEvent_t traced = nullptr;            // (one of `events`, not owned) behind the frame's last tracing kernel, in front of its k_resolve: where the NEXT frame's k_classify may start
         ftk::FrameReport* h_report = nullptr;   // pinned: the frame's statistic stripes, k_classify's error word and the last chunk's rays per bounce,
         ftk::FrameReport* d_report = nullptr;   // written by the frame's last kernel through this device-side address of the same memory
         int levels_launched = 0, last_bounce = 0;
@@ -336,7 +336,7 @@ void ft_destroy(ft_context* c) {
                              &c->d_rays[0], &c->d_rays[1], &c->d_acc[0], &c->d_acc[1], &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc[0], &c->d_fc[1],
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
-        for (auto& f : c->slots) { if (f.traced) { (void)hipEventDestroy(f.traced); f.traced = nullptr; } if (f.h_report) { (void)hipHostFree(f.h_report); f.h_report = nullptr; f.d_report = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
+        for (auto& f : c->slots) { f.traced = nullptr; if (f.h_report) { (void)hipHostFree(f.h_report); f.h_report = nullptr; f.d_report = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
         if (c->classified) (void)hipEventDestroy(c->classified);
         for (hipEvent_t& e : c->acc_free) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (c->side) (void)hipStreamDestroy(c->side);
@@ -989,13 +989,22 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     using Span = ft_context::FrameSlot::Span;
     // HIP events between stages.  An event between two dependent kernels costs about 6 us of stream time, so by default ("timing"
     // = 1) only the kernels that trace rays (k_primary, the k_bounce levels) are bracketed; 2 brackets every stage, 0 only the frame.
-    hipEvent_t ev0 = next_event(F), ev1 = nullptr;
-    if (ev0) (void)hipEventRecord(ev0, c->stream);
-    hipEvent_t boundary = ev0;
-    bool boundary_fresh = true;                                    // `boundary` was recorded right before the next launch
+    // The frame's first event is recorded in front of its first launch on the main stream, behind the waits for other streams' events: on a
+    // queued frame it doubles as the start of k_primary's bracket (an event record costs ~5 us of stream time; a frame of 0.27 ms had four
+    // between two k_primary launches, now two).
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t boundary = nullptr;
+    bool boundary_fresh = false;                                   // `boundary` was recorded right before the next launch
+    auto open_frame = [&]() {
+        if (ev0) return;
+        ev0 = next_event(F);
+        if (ev0) (void)hipEventRecord(ev0, c->stream);
+        boundary = ev0; boundary_fresh = true;
+    };
     const int timing = c->timing;
     auto timed = [&](int kind, auto&& fn) {
         const bool bracket = timing >= 2 || (timing == 1 && (kind == kStageClosest || kind == kStageShade || kind == kStagePrimary));
+        open_frame();
         if (bracket && !boundary_fresh) { boundary = next_event(F); if (boundary) (void)hipEventRecord(boundary, c->stream); }
         fn();
         if (!bracket) { boundary_fresh = false; return; }
@@ -1085,9 +1094,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         };
         if (timing >= 2) bounces(timed);
         else if (n_levels >= 1) timed(kStageShade, [&] { bounces([](int, auto&& fn) { fn(); }); });
-        if (&job == &jobs.back()) {                                // (an event object of the slot's own: next_event's are re-used per frame as well)
-            if (!F.traced) FT_HIP(c, hipEventCreateWithFlags(&F.traced, hipEventDisableTiming));
-            FT_HIP(c, hipEventRecord(F.traced, c->stream));
+        if (&job == &jobs.back()) {                                // where the frame's tracing ends: the event that closed its last bracket, if that is still the stream's last entry
+            if (boundary_fresh && boundary) F.traced = boundary;
+            else { F.traced = next_event(F); if (!F.traced) { c->err = "hipEventCreate failed"; return FT_ERR_HIP; } FT_HIP(c, hipEventRecord(F.traced, c->stream)); }
         }
         if (!aside) for (int k = 0; k < 2; ++k) if (c->acc_busy[k]) {   // a queued frame's k_resolve may still be writing the frame on `tail`: frames reach d_out in order
             FT_HIP(c, hipStreamWaitEvent(c->stream, c->acc_free[k], 0)); c->acc_busy[k] = false; boundary_fresh = false;
@@ -1124,6 +1133,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         if (crc != FT_OK) return crc;
         boundary_fresh = false;
     }
+    open_frame();
     if (aside) { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->tail); }                  // the frame ends where its last k_resolve (and copy) does
     else if (boundary_fresh) ev1 = boundary;
     else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
