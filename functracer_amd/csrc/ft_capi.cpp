@@ -69,6 +69,7 @@ struct ft_context {
     int device = -1;
     int n_cu = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // the second main stream: every other simple queued frame traces here, so that its k_primary is already dispatched when its predecessor's tail frees the CUs
     std::string err;
 
     fth::SceneGraph graph;
@@ -127,6 +128,7 @@ struct ft_context {
         std::vector<hipEvent_t> events; size_t events_used = 0;
         struct Span { hipEvent_t a, b; int kind; };
         std::vector<Span> spans;
+        bool simple = false, alt = false;       // one chunk, k_resolve aside, no reflection levels; traced on the second main stream
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
         hipEvent_t traced = nullptr;            // (one of `events`, not owned) behind the frame's last tracing kernel, in front of its k_resolve: where the NEXT frame's k_classify may start
         ftk::FrameReport* h_report = nullptr;   // pinned: the frame's statistic stripes, k_classify's error word and the last chunk's rays per bounce,
@@ -148,6 +150,7 @@ struct ft_context {
     int64_t active_hint = -1;        // active pixels of the last classified frame retired (and its signature): how wide the next frame's windows may be
     uint64_t active_signature = 0;
     int64_t window_cap = 64ll << 20; // option "window_cap": listed samples a hinted window may span
+    bool two_mains = true;           // option "two_mains": 0 = every frame's tracing kernels on one stream
     bool window_hint = false;        // option "window_hint": 1 widens a classified frame's windows by what the last frame of its signature left inactive (see render_single)
     uint64_t commit_serial = 0;
     bool csg_auto_grow = true;   // ft_render: double csg_mesh_capacity and render again when a hit list overflows
@@ -284,6 +287,7 @@ static int32_t create_single(int32_t device_id, int count, ft_context** out) {
         if (c->side) (void)hipStreamDestroy(c->side);
         (void)hipStreamDestroy(c->stream); delete c; return FT_ERR_HIP;
     }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) c->stream2 = nullptr;   // (without it every frame takes the one main stream)
     c->n_cu = prop.multiProcessorCount;
     *out = c;
     return FT_OK;
@@ -341,6 +345,7 @@ void ft_destroy(ft_context* c) {
         for (hipEvent_t& e : c->acc_free) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (c->side) (void)hipStreamDestroy(c->side);
         if (c->tail) (void)hipStreamDestroy(c->tail);
+        if (c->stream2) (void)hipStreamDestroy(c->stream2);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -361,6 +366,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "window_cap")) { if (value < 64 || value > (1ll << 30)) return FT_ERR_INVALID; c->window_cap = value; for (ft_context* p : c->peers) p->window_cap = value; return FT_OK; }
+    if (!std::strcmp(key, "two_mains")) { c->two_mains = value != 0; for (ft_context* p : c->peers) p->two_mains = value != 0; return FT_OK; }
     if (!std::strcmp(key, "window_hint")) { c->window_hint = value != 0; for (ft_context* p : c->peers) p->window_hint = value != 0; return FT_OK; }
     if (!std::strcmp(key, "resolve_aside")) { c->resolve_aside = value != 0; for (ft_context* p : c->peers) p->resolve_aside = value != 0; return FT_OK; }
     if (!std::strcmp(key, "resolve_blocks")) { if (value < 0 || value > 8) return FT_ERR_INVALID; c->resolve_blocks_cap = (int)value; for (ft_context* p : c->peers) p->resolve_blocks_cap = (int)value; return FT_OK; }
@@ -474,6 +480,7 @@ int32_t ft_scene_add_positional(ft_context* c, const double pos[3], const double
 }
 
 static int32_t upload_scene(ft_context* c);
+static int32_t retire_pending(ft_context* c, ft_stats* stats);
 
 int32_t ft_scene_commit(ft_context* c) {
     if (!c) return FT_ERR_INVALID;
@@ -515,6 +522,8 @@ int32_t ft_get_commit_times(ft_context* c, double ms[4]) {
 static int32_t upload_scene(ft_context* c) {
     int32_t rc;
     FT_HIP(c, hipSetDevice(c->device));
+    // frames still queued trace the scene these uploads replace, and not all of them on the stream the uploads travel on (FrameSlot::alt)
+    if (c->slots[0].pending || c->slots[1].pending) { if ((rc = retire_pending(c, nullptr)) != FT_OK) return rc; c->accum_open = false; }
     const fth::FlatScene& f = c->flat;
     if (lane_fold_for(f) == 0) { c->err = "scene needs more than 160 KiB of LDS per workgroup for CSG lists / BSP stacks even with 4 live lanes per wave"; return FT_ERR_UNSUPPORTED; }
     if ((rc = upload(c, c->d_leaves, f.leaves)) != FT_OK) return rc;
@@ -925,13 +934,17 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         if ((rc = ensure(c, ob, frame_pixels * (q.format == 1 ? 4 : 24))) != FT_OK) return rc;
         if (ob.p != before) c->zero_signature[q.format] = 0;       // a new allocation holds nothing yet
     }
+    std::vector<double> jit;
+    if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
+    else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
+    // The uploads below travel on the first main stream: a frame still tracing on the second one (FrameSlot::alt) reads what they replace.
+    if ((corner || !same_list || jit != c->jitter_on_device) && ((c->slots[0].pending && c->slots[0].alt) || (c->slots[1].pending && c->slots[1].alt))) {
+        int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc;
+    }
     if (corner) {
         if ((rc = upload(c, c->d_pixels, corner_ids)) != FT_OK) return rc;
         if ((rc = upload(c, c->d_out_index, pixels)) != FT_OK) return rc;
     } else if (!same_list) { if ((rc = upload(c, c->d_pixels, pixels)) != FT_OK) return rc; }
-    std::vector<double> jit;
-    if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
-    else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
     bool jitter_uploaded = false;
     if (jit != c->jitter_on_device) {                              // frames usually reuse the pattern: skip the staged host-to-device copy
         c->jitter_on_device = jit;                                 // (the copy source outlives this call)
@@ -961,8 +974,19 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         cls = ftk::ClassifyOut{c->d_block_pos[turn].as<int32_t>(), c->d_pos_block[turn].as<uint32_t>(), c->d_wave_counts.as<uint32_t>()};
     }
     auto* fc = c->d_fc[turn].as<ftk::FrameCounters>();
+    // Which main stream.  Two consecutive k_primary launches on ONE stream are an in-order pair: the second is dispatched when the first has
+    // drained, and a persistent grid drains slowly (its last batches run on a machine that is mostly idle).  A simple frame - one chunk, no
+    // reflection levels, k_resolve aside - shares nothing with its predecessor that events do not already order (sample colours: acc_free;
+    // counters and classification: per slot; the frame buffer: the tail stream), so every other one goes to the second main stream and its
+    // workgroups take the CUs as the predecessor's leave them.
+    const int last_bounce_now = c->flat.any_reflective ? max_depth : 0;
+    const ft_context::FrameSlot& prevF = c->slots[turn ^ 1];
+    const bool simple = defer && c->resolve_aside && !corner && c->timing < 2 && jobs.size() == 1 && last_bounce_now == 0;
+    if (!simple && prevF.pending && prevF.alt) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; }   // anything else keeps the one-stream order
+    const bool alt = simple && c->two_mains && c->stream2 && turn == 1 && !uploads_queued && (!prevF.pending || prevF.simple);
+    const hipStream_t ms = alt ? c->stream2 : c->stream;
     // chunk counters, statistic stripes, list length, tickets: cleared by the slot's previous frame's last kernel, or by a fill when there was none
-    if (!c->fc_clean[turn]) { FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), c->stream)); uploads_queued = true; }
+    if (!c->fc_clean[turn]) { FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), ms)); uploads_queued = true; }
     c->fc_clean[turn] = false;                                     // until this frame's own hand-over is queued
 
     const ftk::Camera dcam = make_camera(*cam, res_h, res_v);
@@ -977,11 +1001,11 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         while (group_log2 < cap && !((spp >> group_log2) & 1)) ++group_log2;
         if (corner || !c->pixels_tiled) group_log2 = 0;
     }
-    ftk::Launch Lp{c->stream, c->n_cu * c->blocks_primary, lds, c->variant_primary};
-    ftk::Launch Lb{c->stream, c->n_cu * c->blocks_bounce, lds, variant};
-    ftk::Launch Lg{c->stream, c->n_cu * 8, 0, 0};
+    ftk::Launch Lp{ms, c->n_cu * c->blocks_primary, lds, c->variant_primary};
+    ftk::Launch Lb{ms, c->n_cu * c->blocks_bounce, lds, variant};
+    ftk::Launch Lg{ms, c->n_cu * 8, 0, 0};
     const int resolve_per_cu = c->resolve_blocks_cap > 0 ? std::min(c->resolve_blocks_cap, c->blocks_resolve) : c->blocks_resolve;
-    ftk::Launch Lr{c->stream, c->n_cu * resolve_per_cu, 0, 0};
+    ftk::Launch Lr{ms, c->n_cu * resolve_per_cu, 0, 0};
     ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
 
     F.events_used = 0; F.spans.clear();
@@ -998,18 +1022,18 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     auto open_frame = [&]() {
         if (ev0) return;
         ev0 = next_event(F);
-        if (ev0) (void)hipEventRecord(ev0, c->stream);
+        if (ev0) (void)hipEventRecord(ev0, ms);
         boundary = ev0; boundary_fresh = true;
     };
     const int timing = c->timing;
     auto timed = [&](int kind, auto&& fn) {
         const bool bracket = timing >= 2 || (timing == 1 && (kind == kStageClosest || kind == kStageShade || kind == kStagePrimary));
         open_frame();
-        if (bracket && !boundary_fresh) { boundary = next_event(F); if (boundary) (void)hipEventRecord(boundary, c->stream); }
+        if (bracket && !boundary_fresh) { boundary = next_event(F); if (boundary) (void)hipEventRecord(boundary, ms); }
         fn();
         if (!bracket) { boundary_fresh = false; return; }
         hipEvent_t b = next_event(F);
-        if (b) (void)hipEventRecord(b, c->stream);
+        if (b) (void)hipEventRecord(b, ms);
         if (boundary && b) spans.push_back(Span{boundary, b, kind});
         boundary = b; boundary_fresh = true;
     };
@@ -1035,7 +1059,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         // frame's k_primary tail and k_resolve instead of behind them.  A blocking frame, or one whose inputs are still being uploaded on
         // the main stream, classifies in line.
         const bool ahead = defer && c->classify_ahead && !uploads_queued;
-        hipStream_t cs = ahead ? c->side : c->stream;
+        hipStream_t cs = ahead ? c->side : ms;
         if (!c->classified) FT_HIP(c, hipEventCreateWithFlags(&c->classified, hipEventDisableTiming));
         else FT_HIP(c, hipStreamWaitEvent(cs, c->classified, 0));  // one classification at a time, whichever streams they are on
         if (ahead) {
@@ -1047,11 +1071,11 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
             const ftk::Launch Ls{c->side, Lg.grid, 0, 0};
             ftk::launch_classify(Ls, c->dev_scene, all, cls, jitter_extent, epoch, fc);
             FT_HIP(c, hipEventRecord(c->classified, c->side));
-            FT_HIP(c, hipStreamWaitEvent(c->stream, c->classified, 0));
+            FT_HIP(c, hipStreamWaitEvent(ms, c->classified, 0));
             boundary_fresh = false;
         } else {
             timed(kStageOther, [&] { ftk::launch_classify(Lg, c->dev_scene, all, cls, jitter_extent, epoch, fc); });
-            FT_HIP(c, hipEventRecord(c->classified, c->stream));
+            FT_HIP(c, hipEventRecord(c->classified, ms));
             boundary_fresh = false;
         }
         ++n_launches;
@@ -1069,7 +1093,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     for (const Job& job : jobs) {
         const uint32_t n_pix = job.n_ids;
         const uint32_t n_samples = n_pix * (uint32_t)spp;
-        if (n_chunks > 0) timed(kStageOther, [&] { (void)hipMemsetAsync(&fc->cc, 0, sizeof(ftk::ChunkCounters), c->stream); });
+        if (n_chunks > 0) timed(kStageOther, [&] { (void)hipMemsetAsync(&fc->cc, 0, sizeof(ftk::ChunkCounters), ms); });
         ++n_chunks;
         ftk::Primary gen{dcam, c->d_pixels.as<uint32_t>(), c->d_jitter.as<double>(), job.id_base, n_pix, spp,
                          (uint32_t)(corner ? res_h + 1 : res_h), (unsigned long long)seed,
@@ -1078,7 +1102,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         gen.group_log2 = (n_pix % 64u == 0u) ? group_log2 : 0;
         const int at = c->acc_turn;
         double* const acc = c->d_acc[at].as<double>();
-        if (c->acc_busy[at]) { FT_HIP(c, hipStreamWaitEvent(c->stream, c->acc_free[at], 0)); c->acc_busy[at] = false; boundary_fresh = false; }   // a k_resolve on `tail` may still be reading this copy
+        if (c->acc_busy[at]) { FT_HIP(c, hipStreamWaitEvent(ms, c->acc_free[at], 0)); c->acc_busy[at] = false; boundary_fresh = false; }   // a k_resolve on `tail` may still be reading this copy
         timed(kStagePrimary, [&] { ftk::launch_primary(Lp, c->dev_scene, gen, rb[1], acc, n_samples, max_depth, fc); });
         ++n_launches;
         // Bounces >= 1: one k_bounce per level of the reflection tree, as many as the previous frame of this signature had (+ 1).
@@ -1096,10 +1120,10 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         else if (n_levels >= 1) timed(kStageShade, [&] { bounces([](int, auto&& fn) { fn(); }); });
         if (&job == &jobs.back()) {                                // where the frame's tracing ends: the event that closed its last bracket, if that is still the stream's last entry
             if (boundary_fresh && boundary) F.traced = boundary;
-            else { F.traced = next_event(F); if (!F.traced) { c->err = "hipEventCreate failed"; return FT_ERR_HIP; } FT_HIP(c, hipEventRecord(F.traced, c->stream)); }
+            else { F.traced = next_event(F); if (!F.traced) { c->err = "hipEventCreate failed"; return FT_ERR_HIP; } FT_HIP(c, hipEventRecord(F.traced, ms)); }
         }
         if (!aside) for (int k = 0; k < 2; ++k) if (c->acc_busy[k]) {   // a queued frame's k_resolve may still be writing the frame on `tail`: frames reach d_out in order
-            FT_HIP(c, hipStreamWaitEvent(c->stream, c->acc_free[k], 0)); c->acc_busy[k] = false; boundary_fresh = false;
+            FT_HIP(c, hipStreamWaitEvent(ms, c->acc_free[k], 0)); c->acc_busy[k] = false; boundary_fresh = false;
         }
         if (corner) timed(kStageResolve, [&] { ftk::launch_resolve_corner(Lg, acc, n_samples, job.w, job.h, c->d_out_index.as<uint32_t>() + job.out_base, out_rgb, out_rgba); });
         else {
@@ -1111,7 +1135,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
                 // behind the chunk's tracing kernels, on its own stream: the main stream goes straight on with the next chunk or frame
                 hipEvent_t et = last_job ? F.traced : next_event(F);
                 if (!et) { c->err = "hipEventCreate failed"; return FT_ERR_HIP; }
-                if (!last_job) FT_HIP(c, hipEventRecord(et, c->stream));
+                if (!last_job) FT_HIP(c, hipEventRecord(et, ms));
                 FT_HIP(c, hipStreamWaitEvent(c->tail, et, 0));
                 ftk::Launch La = Lr; La.stream = c->tail;
                 ftk::launch_resolve(La, ra);
@@ -1128,7 +1152,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     if (!c->fc_clean[turn]) { ftk::launch_report(Lg, fc, F.d_report); c->fc_clean[turn] = true; }   // corner frames end in k_resolve_corner: the hand-over is a launch of its own
     c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v; c->last_format = q.format;
     if (defer && out) {                                            // ft_render_enqueue_into: the frame's way out is queued behind its last kernel
-        const hipStream_t cs = aside ? c->tail : c->stream;
+        const hipStream_t cs = aside ? c->tail : ms;
         int32_t crc = copy_frame_out(c, out, q.format, cs);
         if (crc != FT_OK) return crc;
         boundary_fresh = false;
@@ -1136,9 +1160,10 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     open_frame();
     if (aside) { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->tail); }                  // the frame ends where its last k_resolve (and copy) does
     else if (boundary_fresh) ev1 = boundary;
-    else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, c->stream); }
+    else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, ms); }
     FT_HIP(c, hipGetLastError());
     F.signature = signature; F.levels_launched = levels_launched; F.last_bounce = last_bounce;
+    F.simple = simple; F.alt = alt;
     F.done = ev1;                                                  // nothing follows the last kernel: its end is the frame's
     F.ev0 = ev0; F.ev1 = ev1; F.pending = true; F.wall0 = wall0; F.timing = timing;
     F.rays_primary = 0; for (auto& j : jobs) F.rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;
