@@ -896,7 +896,10 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     uint64_t signature = c->commit_serial * 0x9E3779B97F4A7C15ull;
     for (uint64_t v : {(uint64_t)res_h, (uint64_t)res_v, (uint64_t)spp, (uint64_t)max_depth, (uint64_t)n_pix_total, (uint64_t)c->chunk_samples, (uint64_t)(corner ? 1 : 0)})
         signature = (signature ^ v) * 0x100000001B3ull;
-    int64_t chunk_budget = classify ? 2 * c->chunk_samples : c->chunk_samples;
+    // (round 3: five times as wide, not twice - 80 Mi listed samples.  A frame of one window is a SIMPLE frame below: its k_resolve goes aside and its
+    //  k_primary to the other main stream.  A rank's eighth of 3840x2160x64 - 66 M listed samples, 5 M of them active - was two windows, the
+    //  second one empty: 0.458 -> 0.417 ms per frame as one; its half 1.69 -> 1.62, its quarter and the whole frame unchanged, tools/rank_share_ab.py)
+    int64_t chunk_budget = classify ? 5 * c->chunk_samples : c->chunk_samples;
     // The windows of a classified frame are cut from its LISTED pixels (the host does not know the active list's length when it queues
     // them), so a sparse frame is one window of work and a row of launches that find theirs empty (~20 us each: k_primary + k_resolve +
     // the counter fill; 3840x2160x64 of the bunny: 16 windows, 14 empty).  Option "window_hint" = 1: when the last frame of this
