@@ -150,6 +150,7 @@ struct ft_context {
     int64_t active_hint = -1;        // active pixels of the last classified frame retired (and its signature): how wide the next frame's windows may be
     uint64_t active_signature = 0;
     int64_t window_cap = 64ll << 20; // option "window_cap": listed samples a hinted window may span
+    int64_t primary_reserve = 0;     // option "primary_reserve": workgroup slots a simple frame's k_primary leaves free
     bool two_mains = true;           // option "two_mains": 0 = every frame's tracing kernels on one stream
     bool window_hint = false;        // option "window_hint": 1 widens a classified frame's windows by what the last frame of its signature left inactive (see render_single)
     uint64_t commit_serial = 0;
@@ -366,6 +367,7 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     }
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "window_cap")) { if (value < 64 || value > (1ll << 30)) return FT_ERR_INVALID; c->window_cap = value; for (ft_context* p : c->peers) p->window_cap = value; return FT_OK; }
+    if (!std::strcmp(key, "primary_reserve")) { if (value < 0 || value > 4096) return FT_ERR_INVALID; c->primary_reserve = value; for (ft_context* p : c->peers) p->primary_reserve = value; return FT_OK; }
     if (!std::strcmp(key, "two_mains")) { c->two_mains = value != 0; for (ft_context* p : c->peers) p->two_mains = value != 0; return FT_OK; }
     if (!std::strcmp(key, "window_hint")) { c->window_hint = value != 0; for (ft_context* p : c->peers) p->window_hint = value != 0; return FT_OK; }
     if (!std::strcmp(key, "resolve_aside")) { c->resolve_aside = value != 0; for (ft_context* p : c->peers) p->resolve_aside = value != 0; return FT_OK; }
@@ -1004,7 +1006,11 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
         while (group_log2 < cap && !((spp >> group_log2) & 1)) ++group_log2;
         if (corner || !c->pixels_tiled) group_log2 = 0;
     }
-    ftk::Launch Lp{ms, c->n_cu * c->blocks_primary, lds, c->variant_primary};
+    // Option "primary_reserve": workgroup slots a simple frame's k_primary leaves free for the k_resolve of the frame before and the k_classify
+    // of the frame after, which otherwise get their slots from its tail.  Measured (tools/reserve_sweep.py): the headline is best at 0
+    // (0.2505 ms; 64 free: 0.2545, 256: 0.2715), bunny-bsp12 too; moon x16 gains 3 % at 64.  Default 0.
+    const int reserve = simple && c->primary_reserve > 0 ? (int)c->primary_reserve : 0;
+    ftk::Launch Lp{ms, std::max(c->n_cu, c->n_cu * c->blocks_primary - reserve), lds, c->variant_primary};
     ftk::Launch Lb{ms, c->n_cu * c->blocks_bounce, lds, variant};
     ftk::Launch Lg{ms, c->n_cu * 8, 0, 0};
     const int resolve_per_cu = c->resolve_blocks_cap > 0 ? std::min(c->resolve_blocks_cap, c->blocks_resolve) : c->blocks_resolve;

@@ -151,7 +151,7 @@ const char* ft_last_error(const ft_context* ctx);
  * surface-area split (the best tree, a slow build: 160 ms for 70 K triangles); 1: the device, a linear BVH (1 ms, traces ~9 % slower); 3: the device, a binned surface-area tree
  * over the Morton order (7 ms, traces like the host's); 2 = default: the host below 4096 triangles, the device's surface-area tree from there on),
  * "classify_ahead" / "resolve_aside" / "zero_fill_skip" (1 = default: what a stream of queued frames does that a single frame cannot - the next frame's k_classify on a second
- * stream, k_resolve on a third with the sample colours double-buffered, Colour.Zero not written again into blocks the last frame of the same signature left zero; 0 switches each off; k_resolve goes aside only in frames of one chunk), "window_hint" (0 = default; 1: the chunks of a
+ * stream, k_resolve on a third with the sample colours double-buffered, Colour.Zero not written again into blocks the last frame of the same signature left zero; 0 switches each off; k_resolve goes aside only in frames of one chunk), "two_mains" (1 = default: queued frames of one chunk without reflection levels alternate between two main streams, so a frame's k_primary is dispatched while its predecessor's drains; 0: one main stream), "primary_reserve" (0 = default: workgroup slots such a frame's k_primary leaves free for the small kernels queued beside it), "window_hint" (0 = default; 1: the chunks of a
  * classified frame are cut as wide as the last frame of the same scene, size and sample count left them room for, up to "window_cap" listed samples - fewer empty launches on sparse frames, measured no net gain), "wave_samples" (0 = default, 16: a bounce-0 wavefront takes up to that many jitter offsets of 64 / that many pixels of an
  * 8x8 block when the sample count has the power of two in it - a narrower bundle; 1, 2, 4, 8, 16; no pixel depends on it).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
