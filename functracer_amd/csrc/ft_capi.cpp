@@ -96,7 +96,8 @@ struct ft_context {
     DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_wave_counts, d_wide, d_mesh_wide, d_coarse;
     // What k_classify writes and the frame's later kernels read exists once per frame slot, so that a queued frame's classification can
     // run (on `side`, behind an event) while the frame before it is still tracing: block_pos / pos_block and the frame's counters.
-    DeviceBuf d_block_pos[2], d_pos_block[2], d_fc[2];
+    static constexpr int kSlots = 3;   // frames in flight: N traced, N + 1 dispatched behind it on the other main stream, N + 2 classified ahead
+    DeviceBuf d_block_pos[kSlots], d_pos_block[kSlots], d_fc[kSlots];
     hipStream_t side = nullptr;     // the second stream: k_classify of frame N + 1 beside k_primary's tail / k_resolve of frame N (ft_render_enqueue)
     bool classify_ahead = true;     // option "classify_ahead": 0 keeps every kernel on the one stream
     bool classify_after_trace = false;   // option "classify_after_trace": the classification run ahead waits for the previous frame's tracing kernels
@@ -116,7 +117,7 @@ struct ft_context {
     hipEvent_t acc_free[2] = {nullptr, nullptr};
     bool acc_busy[2] = {false, false};
     bool resolve_aside = true;      // option "resolve_aside": 0 keeps k_resolve on the main stream
-    bool fc_clean[2] = {false, false};   // d_fc[slot] is all zero: the slot's previous frame cleared it behind its report (no fill needed)
+    bool fc_clean[kSlots] = {false, false, false};   // d_fc[slot] is all zero: the slot's previous frame cleared it behind its report (no fill needed)
     // Colour.Zero in the blocks k_classify finished: what the last frame written into d_out / d_out8 classified (scene, camera, size, pixel
     // list, jitter extent).  A frame of the same signature finds those pixels zero already and does not write them again.
     uint64_t zero_signature[2] = {0, 0};
@@ -139,7 +140,7 @@ struct ft_context {
         uint64_t rays_primary = 0; int64_t n_pix_total = 0; int32_t spp = 0, n_launches = 0, n_chunks = 0, timing = 1, format = 0; bool classify = false;
         std::chrono::steady_clock::time_point wall0;
     };
-    FrameSlot slots[2];
+    FrameSlot slots[kSlots];
     int slot_turn = 0;
     // Levels of the reflection tree worth launching: the host cannot know how deep the rays of a frame go without waiting, and a
     // k_bounce launch that finds no rays still costs a few microseconds.  It launches as many levels as the previous frame of the
@@ -337,7 +338,7 @@ void ft_destroy(ft_context* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (c->side) (void)hipStreamSynchronize(c->side);
         if (c->tail) (void)hipStreamSynchronize(c->tail);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos[0], &c->d_block_pos[1], &c->d_pos_block[0], &c->d_pos_block[1], &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos[0], &c->d_block_pos[1], &c->d_block_pos[2], &c->d_pos_block[0], &c->d_pos_block[1], &c->d_pos_block[2], &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
                              &c->d_rays[0], &c->d_rays[1], &c->d_acc[0], &c->d_acc[1], &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc[0], &c->d_fc[1],
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
@@ -483,6 +484,7 @@ int32_t ft_scene_add_positional(ft_context* c, const double pos[3], const double
 
 static int32_t upload_scene(ft_context* c);
 static int32_t retire_pending(ft_context* c, ft_stats* stats);
+static bool any_pending(const ft_context* c, bool on_second_main = false) { for (const auto& f : c->slots) if (f.pending && (!on_second_main || f.alt)) return true; return false; }
 
 int32_t ft_scene_commit(ft_context* c) {
     if (!c) return FT_ERR_INVALID;
@@ -525,7 +527,7 @@ static int32_t upload_scene(ft_context* c) {
     int32_t rc;
     FT_HIP(c, hipSetDevice(c->device));
     // frames still queued trace the scene these uploads replace, and not all of them on the stream the uploads travel on (FrameSlot::alt)
-    if (c->slots[0].pending || c->slots[1].pending) { if ((rc = retire_pending(c, nullptr)) != FT_OK) return rc; c->accum_open = false; }
+    if (any_pending(c)) { if ((rc = retire_pending(c, nullptr)) != FT_OK) return rc; c->accum_open = false; }
     const fth::FlatScene& f = c->flat;
     if (lane_fold_for(f) == 0) { c->err = "scene needs more than 160 KiB of LDS per workgroup for CSG lists / BSP stacks even with 4 live lanes per wave"; return FT_ERR_UNSUPPORTED; }
     if ((rc = upload(c, c->d_leaves, f.leaves)) != FT_OK) return rc;
@@ -558,7 +560,7 @@ static int32_t upload_scene(ft_context* c) {
     if ((rc = upload(c, c->d_mesh_wide, f.mesh_wide)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_coarse, f.coarse_boxes)) != FT_OK) return rc;
     if ((rc = upload(c, c->d_tri_orig, f.tri_orig)) != FT_OK) return rc;
-    for (int k = 0; k < 2; ++k) { if ((rc = ensure(c, c->d_fc[k], sizeof(ftk::FrameCounters))) != FT_OK) return rc; c->fc_clean[k] = false; }
+    for (int k = 0; k < ft_context::kSlots; ++k) { if ((rc = ensure(c, c->d_fc[k], sizeof(ftk::FrameCounters))) != FT_OK) return rc; c->fc_clean[k] = false; }
     c->zero_signature[0] = c->zero_signature[1] = 0;
     FT_HIP(c, hipStreamSynchronize(c->stream));
     {   // the BVHs the flattener left to the device (ft_bvh.hip), straight into the ranges reserved in the arrays just uploaded
@@ -714,7 +716,7 @@ static int32_t with_growing_hit_lists(ft_context* c, const std::function<int32_t
         std::vector<ft_context*> devs{c};
         devs.insert(devs.end(), c->peers.begin(), c->peers.end());
         for (ft_context* d : devs) {
-            if (!d->slots[0].pending && !d->slots[1].pending) continue;
+            if (!any_pending(d)) continue;
             if (hipSetDevice(d->device) != hipSuccess) { c->err = "hipSetDevice failed"; return FT_ERR_NO_DEVICE; }
             const int32_t prc = retire_pending(d, nullptr);
             d->accum_open = false;
@@ -943,7 +945,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
     else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
     // The uploads below travel on the first main stream: a frame still tracing on the second one (FrameSlot::alt) reads what they replace.
-    if ((corner || !same_list || jit != c->jitter_on_device) && ((c->slots[0].pending && c->slots[0].alt) || (c->slots[1].pending && c->slots[1].alt))) {
+    if ((corner || !same_list || jit != c->jitter_on_device) && any_pending(c, true)) {
         int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc;
     }
     if (corner) {
@@ -985,10 +987,10 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     // counters and classification: per slot; the frame buffer: the tail stream), so every other one goes to the second main stream and its
     // workgroups take the CUs as the predecessor's leave them.
     const int last_bounce_now = c->flat.any_reflective ? max_depth : 0;
-    const ft_context::FrameSlot& prevF = c->slots[turn ^ 1];
+    const ft_context::FrameSlot& prevF = c->slots[(turn + ft_context::kSlots - 1) % ft_context::kSlots];
     const bool simple = defer && c->resolve_aside && !corner && c->timing < 2 && jobs.size() == 1 && last_bounce_now == 0;
-    if (!simple && prevF.pending && prevF.alt) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; }   // anything else keeps the one-stream order
-    const bool alt = simple && c->two_mains && c->stream2 && turn == 1 && !uploads_queued && (!prevF.pending || prevF.simple);
+    if (!simple && any_pending(c, true)) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; }   // anything else keeps the one-stream order
+    const bool alt = simple && c->two_mains && c->stream2 && !uploads_queued && prevF.pending && prevF.simple && !prevF.alt;   // the other stream than its predecessor's
     const hipStream_t ms = alt ? c->stream2 : c->stream;
     // chunk counters, statistic stripes, list length, tickets: cleared by the slot's previous frame's last kernel, or by a fill when there was none
     if (!c->fc_clean[turn]) { FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), ms)); uploads_queued = true; }
@@ -1075,7 +1077,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
             // beside the previous frame's k_resolve (a bandwidth-bound kernel that leaves registers free), not beside the head of its
             // k_primary: started as soon as it was queued, the classification took the first workgroup slots of a grid that fills the chip
             // (measured: k_primary 226 -> 242 us, the 24 us merely moved)
-            const ft_context::FrameSlot& prev = c->slots[turn ^ 1];
+            const ft_context::FrameSlot& prev = c->slots[(turn + ft_context::kSlots - 1) % ft_context::kSlots];
             if (c->classify_after_trace && prev.pending && prev.traced) FT_HIP(c, hipStreamWaitEvent(c->side, prev.traced, 0));
             const ftk::Launch Ls{c->side, Lg.grid, 0, 0};
             ftk::launch_classify(Ls, c->dev_scene, all, cls, jitter_extent, epoch, fc);
@@ -1178,7 +1180,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     F.rays_primary = 0; for (auto& j : jobs) F.rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;
     F.n_pix_total = n_pix_total; F.spp = spp; F.n_launches = n_launches; F.n_chunks = n_chunks; F.classify = classify; F.format = q.format;
     c->last_n_pix = n_pix_total; c->last_res_h = res_h; c->last_res_v = res_v; c->last_format = q.format;
-    c->slot_turn ^= 1;
+    c->slot_turn = (c->slot_turn + 1) % ft_context::kSlots;
     if (defer) return FT_OK;                                       // ft_render_enqueue: the frame is retired by a later call
     int32_t rrc = retire_frame(c, F, stats);
     if (rrc != FT_OK) return rrc;
@@ -1253,11 +1255,13 @@ static int32_t retire_frame(ft_context* c, ft_context::FrameSlot& F, ft_stats* s
 
 // Retire every queued frame, oldest first; `stats` receives the newest one's.
 static int32_t retire_pending(ft_context* c, ft_stats* stats) {
-    ft_context::FrameSlot& older = c->slots[c->slot_turn];
-    ft_context::FrameSlot& newer = c->slots[c->slot_turn ^ 1];
     int32_t rc = FT_OK;
-    if (older.pending) { int32_t r = retire_frame(c, older, newer.pending ? nullptr : stats); if (r != FT_OK) rc = r; }
-    if (newer.pending) { int32_t r = retire_frame(c, newer, stats); if (r != FT_OK) rc = r; }
+    int last = -1;
+    for (int k = 0; k < ft_context::kSlots; ++k) if (c->slots[(c->slot_turn + k) % ft_context::kSlots].pending) last = k;
+    for (int k = 0; k < ft_context::kSlots; ++k) {                  // oldest first; the statistics asked for are the newest frame's
+        ft_context::FrameSlot& f = c->slots[(c->slot_turn + k) % ft_context::kSlots];
+        if (f.pending) { int32_t r = retire_frame(c, f, k == last ? stats : nullptr); if (r != FT_OK) rc = r; }
+    }
     return rc;
 }
 
