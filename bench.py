@@ -252,16 +252,16 @@ def main():
     # (ft_render_enqueue_into, two buffers in turn): the copy of frame N travels while frame N + 1 is traced.
     streaming = {}
     for mode in (() if args.no_boundary else ("f64", "rgba8")):
-        shape, dt = ((2, res_v, res_h, 3), np.float64) if mode == "f64" else ((2, res_v, res_h, 4), np.uint8)
+        shape, dt = ((4, res_v, res_h, 3), np.float64) if mode == "f64" else ((4, res_v, res_h, 4), np.uint8)   # three frames in flight + the one the host would be reading
         with ft.PinnedArray(shape, dtype=dt) as ring:
             for k in range(4):
-                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k & 1])
+                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k & 3])
             ctx.wait()
             barrier_sync()
             ts = time.perf_counter()
             n_s = 30
             for k in range(n_s):
-                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k & 1])
+                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k & 3])
             ctx.wait()
             barrier_sync()
             (s_wall,), _ = reduce_max_sum([time.perf_counter() - ts], [0.0])
@@ -296,6 +296,9 @@ def main():
                 "frame_model": {"bytes_per_frame": int(frame_bytes), "GBps": round(frame_bytes / kernel_s / 1e9, 2), "frac": round(frame_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS, 6),
                                 "note": "8(d)'s whole-frame form: (192 x rays_traced + 24 x pixels) / kernel seconds of the frame"},
                 "note": "the path is FP64 vector-ALU / latency bound, not HBM bound (DESIGN.md 5): `real_bound` is the fraction that says how well the kernel uses the chip"}
+        roof["pipelined"] = {"GBps": round(survey_bytes * launches_per_step / (ms_per_step * 1e-3) / 1e9, 2), "frac": round(survey_bytes * launches_per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                             "note": "the same bytes over the frame PERIOD: queued frames overlap (a frame's k_primary is dispatched on a second stream while its predecessor's drains), "
+                                     "so a launch's own duration counts the stretch it shares the CUs with its neighbours twice"}
         if alone.get(dom):
             roof["alone"] = {"avg_launch_ms": round(alone[dom], 4), "GBps": round(survey_bytes / (alone[dom] * 1e-3) / 1e9, 2),
                              "frac": round(survey_bytes / (alone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
@@ -349,7 +352,7 @@ def main():
             "gather_ms": round(gather_ms, 3),
             "roofline": roof,
             "per_kernel_ms_per_step": {k: round(v / steps, 4) for k, v in k_times.items()},
-            "per_kernel_note": "HIP-event brackets on the main stream; queued frames overlap (the next frame's k_classify and this frame's k_resolve run on side streams beside k_primary), "
+            "per_kernel_note": "HIP-event brackets on the frame's main stream; queued frames overlap (the next frames' k_classify and k_primary and the last frame's k_resolve run on other streams beside k_primary), "
                                "so `other` is what of a frame's own span its tracing kernels do not cover, not time added to the frame period: ms_per_step minus the dominant kernel is that",
             "frame_period_minus_dominant_kernel_ms": round(ms_per_step - dom_avg_ms * launches_per_step, 4),
             "per_kernel_launches_per_step": {k: round(v / steps, 3) for k, v in k_launch.items()},

@@ -944,8 +944,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     std::vector<double> jit;
     if (corner) jit = {-0.5, 0.5};                                 // Image.fs:131
     else jit.assign(jitter_xy, jitter_xy + 2 * (size_t)spp);
-    // The uploads below travel on the first main stream: a frame still tracing on the second one (FrameSlot::alt) reads what they replace.
-    if ((corner || !same_list || jit != c->jitter_on_device) && any_pending(c, true)) {
+    // The uploads below travel on the first main stream: a frame still tracing on the second one (FrameSlot::alt), or one whose k_resolve is
+    // still to run on the tail stream (it reads the pixel list), reads what they replace.
+    if ((corner || !same_list || jit != c->jitter_on_device) && any_pending(c)) {
         int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc;
     }
     if (corner) {

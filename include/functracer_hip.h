@@ -224,13 +224,15 @@ void  ft_host_free(void* p);
 
 /* A queued frame that also leaves the device: the copy into host_out (res_v x res_h x 3 doubles, or x 4 bytes with rgba8 != 0) is queued
  * behind the frame's last kernel and is complete when ft_render_wait returns (or when a later call retires the frame).  host_out should
- * come from ft_host_alloc (one DMA beside the next frame's tracing); one buffer per frame in flight (two at most). */
+ * come from ft_host_alloc (one DMA beside the next frame's tracing); one buffer per frame in flight (three at most: a buffer is the host's again once
+ * a later call has retired its frame - queuing frame k + 3 retires frame k - or ft_render_wait has returned). */
 int32_t ft_render_enqueue_into(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                                int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, int32_t rgba8, void* host_out);
 
 /* Pipelined rendering, for hosts that render frame after frame (an animation, a progressive preview):
  * ft_render_enqueue queues a frame exactly as ft_render(out_rgb = NULL) would and returns without waiting, so the host prepares
- * the next frame while this one runs; at most two frames are in flight (queuing a third first waits for the oldest).  On a context
+ * the next frame while this one runs; at most three frames are in flight (queuing a fourth first waits for the oldest: one is traced, the next is
+ * dispatched behind it on a second stream, the third is being classified).  On a context
  * over several devices every device queues its bands on its own stream; ft_render_wait waits for all of them and sums their statistics.
  * ft_render_wait blocks until everything queued has finished, reports the statistics of the LAST frame, and leaves in
  * ft_get_kernel_times the stage times and launch counts summed over all frames since the previous wait.  The frame buffer holds

@@ -955,6 +955,41 @@ def test_pipelined_frames_equal_blocking_frames(hip):
     assert hip.wait()["rays_traced"] == 0                         # nothing queued
 
 
+def test_three_frames_in_flight_on_two_main_streams(hip):
+    """Queued frames of one chunk without reflection levels are SIMPLE frames (frame pipeline): three in flight, their k_primary
+    launches alternating between two main streams, k_classify a frame ahead, k_resolve and the copy out behind on a third.  Seven frames from
+    three cameras, each delivered into its own page-locked buffer, FP64 and RGBA8 mixed, a tile list and an upload (new jitter pattern) in
+    between: every buffer must hold its frame's blocking twin, whatever the option says."""
+    p = _load("bunny")
+    p.lower(hip)
+    w, h, spp = 256, 192, 4
+    jit, jit2 = ft.jitter_pattern(spp), ft.jitter_pattern(spp, seed=99)
+    cams = [ft.make_camera((0.0, 0.9, -7.0), (x, 0.7, 0.0), (0, 1, 0), H.deg(40.0)) for x in (0.6, -0.9, 0.0)]
+    left = [(0, 0, 128, 192)]
+    plan = [(0, jit, None, False), (1, jit, None, False), (2, jit, None, True), (0, jit, None, False), (1, jit2, None, False), (2, jit2, left, False), (0, jit, None, True)]
+    hip.set_option("two_mains", 0)
+    want = []
+    for cam, j, tiles, rgba8 in plan:
+        if rgba8:
+            want.append(hip.render_rgba8(cams[cam], w, h, spp, j)[0])
+        else:
+            full = np.full((h, w, 3), -5.0)
+            hip.render(cams[cam], w, h, spp, j, tiles=tiles, out=full)
+            want.append(full)
+    for two in (1, 0):
+        hip.set_option("two_mains", two)
+        with ft.PinnedArray((len(plan), h, w, 3)) as f64, ft.PinnedArray((len(plan), h, w, 4), dtype=np.uint8) as u8:
+            f64[:] = -5.0
+            for rep in range(2):                                    # the second round starts with three frames of the first still in flight
+                for k, (cam, j, tiles, rgba8) in enumerate(plan):
+                    hip.render_enqueue(cams[cam], w, h, spp, j, tiles=tiles, rgba8=rgba8, out=u8[k] if rgba8 else f64[k])
+            st = hip.wait()
+            for k, (cam, j, tiles, rgba8) in enumerate(plan):
+                assert np.array_equal(u8[k] if rgba8 else f64[k], want[k]), (two, k)
+            assert st["rays_primary"] == w * h * spp
+    hip.set_option("two_mains", 1)
+
+
 def test_zero_fill_skip_and_classification_ahead_change_no_pixel(hip):
     """Two things a stream of frames does that a single frame does not: a queued frame's k_classify runs on a second stream
     beside the frame before it, and Colour.Zero is not written again into blocks the last frame of the same signature (scene, camera,
