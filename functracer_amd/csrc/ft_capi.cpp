@@ -108,7 +108,7 @@ struct ft_context {
     hipEvent_t classified = nullptr;  // behind the latest k_classify on either stream: the next one waits for it (they share the ticket words of d_wave_counts)
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
-    DeviceBuf d_rays[2], d_acc[2], d_out, d_out8, d_pixels, d_jitter, d_dbg_in, d_dbg_out;
+    DeviceBuf d_rays[4], d_acc[2], d_out, d_out8, d_pixels, d_jitter, d_dbg_in, d_dbg_out;
     // The sample colours exist twice: a queued frame's k_resolve runs on a stream of its own (`tail`), behind an event, while the next
     // chunk's / frame's k_primary already fills the other copy - the small kernel hides in the big one's ramp instead of standing between
     // two of them.  acc_free[i]: behind the last k_resolve that read copy i (the next k_primary into that copy waits for it).
@@ -129,7 +129,7 @@ struct ft_context {
         std::vector<hipEvent_t> events; size_t events_used = 0;
         struct Span { hipEvent_t a, b; int kind; };
         std::vector<Span> spans;
-        bool simple = false, alt = false;       // one chunk, k_resolve aside, no reflection levels; traced on the second main stream
+        bool simple = false, alt = false;       // one chunk, k_resolve aside; traced on the second main stream
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
         hipEvent_t traced = nullptr;            // (one of `events`, not owned) behind the frame's last tracing kernel, in front of its k_resolve: where the NEXT frame's k_classify may start
         ftk::FrameReport* h_report = nullptr;   // pinned: the frame's statistic stripes, k_classify's error word and the last chunk's rays per bounce,
@@ -216,7 +216,7 @@ int32_t ensure_frame_buffers(ft_context* c, int64_t cap, bool reflective) {
     int32_t rc;
     if (cap > c->acc_capacity) { for (int k = 0; k < 2; ++k) if ((rc = ensure(c, c->d_acc[k], (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
     if (!reflective || cap <= c->ray_capacity) return FT_OK;
-    for (int i = 0; i < 2; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;
+    for (int i = 0; i < 4; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;   // a ping-pong pair per main stream
     c->ray_capacity = cap;
     return FT_OK;
 }
@@ -339,7 +339,7 @@ void ft_destroy(ft_context* c) {
         if (c->side) (void)hipStreamSynchronize(c->side);
         if (c->tail) (void)hipStreamSynchronize(c->tail);
         DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos[0], &c->d_block_pos[1], &c->d_block_pos[2], &c->d_pos_block[0], &c->d_pos_block[1], &c->d_pos_block[2], &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
-                             &c->d_rays[0], &c->d_rays[1], &c->d_acc[0], &c->d_acc[1], &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc[0], &c->d_fc[1],
+                             &c->d_rays[0], &c->d_rays[1], &c->d_rays[2], &c->d_rays[3], &c->d_acc[0], &c->d_acc[1], &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc[0], &c->d_fc[1], &c->d_fc[2],
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
         for (auto& f : c->slots) { f.traced = nullptr; if (f.h_report) { (void)hipHostFree(f.h_report); f.h_report = nullptr; f.d_report = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
@@ -983,13 +983,12 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     }
     auto* fc = c->d_fc[turn].as<ftk::FrameCounters>();
     // Which main stream.  Two consecutive k_primary launches on ONE stream are an in-order pair: the second is dispatched when the first has
-    // drained, and a persistent grid drains slowly (its last batches run on a machine that is mostly idle).  A simple frame - one chunk, no
-    // reflection levels, k_resolve aside - shares nothing with its predecessor that events do not already order (sample colours: acc_free;
-    // counters and classification: per slot; the frame buffer: the tail stream), so every other one goes to the second main stream and its
+    // drained, and a persistent grid drains slowly (its last batches run on a machine that is mostly idle).  A simple frame - one chunk,
+    // k_resolve aside - shares nothing with its predecessor that events do not already order (sample colours: acc_free; counters and
+    // classification: per slot; the frame buffer: the tail stream; ray buffers: a pair per main stream), so every other one goes to the second main stream and its
     // workgroups take the CUs as the predecessor's leave them.
-    const int last_bounce_now = c->flat.any_reflective ? max_depth : 0;
     const ft_context::FrameSlot& prevF = c->slots[(turn + ft_context::kSlots - 1) % ft_context::kSlots];
-    const bool simple = defer && c->resolve_aside && !corner && c->timing < 2 && jobs.size() == 1 && last_bounce_now == 0;
+    const bool simple = defer && c->resolve_aside && !corner && c->timing < 2 && jobs.size() == 1;
     if (!simple && any_pending(c, true)) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; }   // anything else keeps the one-stream order
     const bool alt = simple && c->two_mains && c->stream2 && !uploads_queued && prevF.pending && prevF.simple && !prevF.alt;   // the other stream than its predecessor's
     const hipStream_t ms = alt ? c->stream2 : c->stream;
@@ -1018,7 +1017,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     ftk::Launch Lg{ms, c->n_cu * 8, 0, 0};
     const int resolve_per_cu = c->resolve_blocks_cap > 0 ? std::min(c->resolve_blocks_cap, c->blocks_resolve) : c->blocks_resolve;
     ftk::Launch Lr{ms, c->n_cu * resolve_per_cu, 0, 0};
-    ftk::RayBuf rb[2] = {ray_view(c->d_rays[0], c->ray_capacity), ray_view(c->d_rays[1], c->ray_capacity)};
+    ftk::RayBuf rb[2] = {ray_view(c->d_rays[alt ? 2 : 0], c->ray_capacity), ray_view(c->d_rays[alt ? 3 : 1], c->ray_capacity)};
 
     F.events_used = 0; F.spans.clear();
     auto& spans = F.spans;
