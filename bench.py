@@ -252,16 +252,16 @@ def main():
     # (ft_render_enqueue_into, two buffers in turn): the copy of frame N travels while frame N + 1 is traced.
     streaming = {}
     for mode in (() if args.no_boundary else ("f64", "rgba8")):
-        shape, dt = ((4, res_v, res_h, 3), np.float64) if mode == "f64" else ((4, res_v, res_h, 4), np.uint8)   # three frames in flight + the one the host would be reading
+        shape, dt = ((5, res_v, res_h, 3), np.float64) if mode == "f64" else ((5, res_v, res_h, 4), np.uint8)   # four frames in flight + the one the host would be reading
         with ft.PinnedArray(shape, dtype=dt) as ring:
-            for k in range(4):
-                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k & 3])
+            for k in range(5):
+                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k % 5])
             ctx.wait()
             barrier_sync()
             ts = time.perf_counter()
             n_s = 30
             for k in range(n_s):
-                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k & 3])
+                ctx.render_enqueue(scene.camera, res_h, res_v, spp, P["jitter"], tiles=P["bands"], rgba8=mode == "rgba8", out=ring[k % 5])
             ctx.wait()
             barrier_sync()
             (s_wall,), _ = reduce_max_sum([time.perf_counter() - ts], [0.0])

@@ -63,13 +63,14 @@ struct DeviceWorker {
 
 constexpr int64_t kDeviceBvhMinTris = 4096;   // "bvh_builder" = 2: smaller meshes get the host's swept SAH tree (a few ms at most), larger ones the device's binned one
 struct ft_context {
+    static constexpr int kMains_minus_1 = 2;
     std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
     std::vector<DeviceWorker*> workers;  // ... and one host thread per peer
     bool host_only = false;
     int device = -1;
     int n_cu = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // the second main stream: every other simple queued frame traces here, so that its k_primary is already dispatched when its predecessor's tail frees the CUs
+    hipStream_t more_mains[kMains_minus_1] = {};   // further main streams: consecutive simple queued frames trace on different ones, so that a frame's kernels are dispatched while its predecessors' drain
     std::string err;
 
     fth::SceneGraph graph;
@@ -96,7 +97,9 @@ struct ft_context {
     DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_wave_counts, d_wide, d_mesh_wide, d_coarse;
     // What k_classify writes and the frame's later kernels read exists once per frame slot, so that a queued frame's classification can
     // run (on `side`, behind an event) while the frame before it is still tracing: block_pos / pos_block and the frame's counters.
-    static constexpr int kSlots = 3;   // frames in flight: N traced, N + 1 dispatched behind it on the other main stream, N + 2 classified ahead
+    static constexpr int kMains = 3;   // main streams: consecutive simple frames trace on different ones
+    static constexpr int kAcc = kMains;   // copies of the sample colours: one per frame between its k_primary and its k_resolve
+    static constexpr int kSlots = kMains + 1;   // frames in flight: one per main stream + the one being classified ahead
     DeviceBuf d_block_pos[kSlots], d_pos_block[kSlots], d_fc[kSlots];
     hipStream_t side = nullptr;     // the second stream: k_classify of frame N + 1 beside k_primary's tail / k_resolve of frame N (ft_render_enqueue)
     bool classify_ahead = true;     // option "classify_ahead": 0 keeps every kernel on the one stream
@@ -108,16 +111,16 @@ struct ft_context {
     hipEvent_t classified = nullptr;  // behind the latest k_classify on either stream: the next one waits for it (they share the ticket words of d_wave_counts)
     ftk::DevScene dev_scene{};
     // frame buffers in HBM
-    DeviceBuf d_rays[4], d_acc[2], d_out, d_out8, d_pixels, d_jitter, d_dbg_in, d_dbg_out;
+    DeviceBuf d_rays[2 * kMains], d_acc[kAcc], d_out, d_out8, d_pixels, d_jitter, d_dbg_in, d_dbg_out;
     // The sample colours exist twice: a queued frame's k_resolve runs on a stream of its own (`tail`), behind an event, while the next
     // chunk's / frame's k_primary already fills the other copy - the small kernel hides in the big one's ramp instead of standing between
     // two of them.  acc_free[i]: behind the last k_resolve that read copy i (the next k_primary into that copy waits for it).
     int acc_turn = 0;
     hipStream_t tail = nullptr;
-    hipEvent_t acc_free[2] = {nullptr, nullptr};
-    bool acc_busy[2] = {false, false};
+    hipEvent_t acc_free[kAcc] = {};
+    bool acc_busy[kAcc] = {};
     bool resolve_aside = true;      // option "resolve_aside": 0 keeps k_resolve on the main stream
-    bool fc_clean[kSlots] = {false, false, false};   // d_fc[slot] is all zero: the slot's previous frame cleared it behind its report (no fill needed)
+    bool fc_clean[kSlots] = {};   // d_fc[slot] is all zero: the slot's previous frame cleared it behind its report (no fill needed)
     // Colour.Zero in the blocks k_classify finished: what the last frame written into d_out / d_out8 classified (scene, camera, size, pixel
     // list, jitter extent).  A frame of the same signature finds those pixels zero already and does not write them again.
     uint64_t zero_signature[2] = {0, 0};
@@ -129,7 +132,8 @@ struct ft_context {
         std::vector<hipEvent_t> events; size_t events_used = 0;
         struct Span { hipEvent_t a, b; int kind; };
         std::vector<Span> spans;
-        bool simple = false, alt = false;       // one chunk, k_resolve aside; traced on the second main stream
+        bool simple = false, alt = false;       // one chunk, k_resolve aside; alt: traced on main stream `main_ix` != 0
+        int main_ix = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
         hipEvent_t traced = nullptr;            // (one of `events`, not owned) behind the frame's last tracing kernel, in front of its k_resolve: where the NEXT frame's k_classify may start
         ftk::FrameReport* h_report = nullptr;   // pinned: the frame's statistic stripes, k_classify's error word and the last chunk's rays per bounce,
@@ -152,7 +156,7 @@ struct ft_context {
     uint64_t active_signature = 0;
     int64_t window_cap = 64ll << 20; // option "window_cap": listed samples a hinted window may span
     int64_t primary_reserve = 0;     // option "primary_reserve": workgroup slots a simple frame's k_primary leaves free
-    bool two_mains = true;           // option "two_mains": 0 = every frame's tracing kernels on one stream
+    int mains = 2;                   // option "mains" (1 .. 3): main streams in use (measured: 2 is best - the headline 0.263 / 0.231 / 0.249 ms with 1 / 2 / 3, hollow-sphere x1 0.703 / 0.471 / 0.470); "two_mains" = 0 is mains = 1
     bool window_hint = false;        // option "window_hint": 1 widens a classified frame's windows by what the last frame of its signature left inactive (see render_single)
     uint64_t commit_serial = 0;
     bool csg_auto_grow = true;   // ft_render: double csg_mesh_capacity and render again when a hit list overflows
@@ -214,9 +218,9 @@ ftk::RayBuf ray_view(const DeviceBuf& b, int64_t cap) {
 // Per-sample accumulators for every frame; the ray wavefront buffers only for scenes with reflective materials (bounce >= 1).
 int32_t ensure_frame_buffers(ft_context* c, int64_t cap, bool reflective) {
     int32_t rc;
-    if (cap > c->acc_capacity) { for (int k = 0; k < 2; ++k) if ((rc = ensure(c, c->d_acc[k], (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
+    if (cap > c->acc_capacity) { for (int k = 0; k < ft_context::kAcc; ++k) if ((rc = ensure(c, c->d_acc[k], (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
     if (!reflective || cap <= c->ray_capacity) return FT_OK;
-    for (int i = 0; i < 4; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;   // a ping-pong pair per main stream
+    for (int i = 0; i < 2 * ft_context::kMains; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;   // a ping-pong pair per main stream
     c->ray_capacity = cap;
     return FT_OK;
 }
@@ -289,7 +293,7 @@ static int32_t create_single(int32_t device_id, int count, ft_context** out) {
         if (c->side) (void)hipStreamDestroy(c->side);
         (void)hipStreamDestroy(c->stream); delete c; return FT_ERR_HIP;
     }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) c->stream2 = nullptr;   // (without it every frame takes the one main stream)
+    for (hipStream_t& m : c->more_mains) if (hipStreamCreateWithFlags(&m, hipStreamNonBlocking) != hipSuccess) { m = nullptr; c->mains = 1; }   // (without them every frame takes the one main stream)
     c->n_cu = prop.multiProcessorCount;
     *out = c;
     return FT_OK;
@@ -338,8 +342,8 @@ void ft_destroy(ft_context* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (c->side) (void)hipStreamSynchronize(c->side);
         if (c->tail) (void)hipStreamSynchronize(c->tail);
-        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos[0], &c->d_block_pos[1], &c->d_block_pos[2], &c->d_pos_block[0], &c->d_pos_block[1], &c->d_pos_block[2], &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
-                             &c->d_rays[0], &c->d_rays[1], &c->d_rays[2], &c->d_rays[3], &c->d_acc[0], &c->d_acc[1], &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc[0], &c->d_fc[1], &c->d_fc[2],
+        DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos[0], &c->d_block_pos[1], &c->d_block_pos[2], &c->d_block_pos[3], &c->d_pos_block[0], &c->d_pos_block[1], &c->d_pos_block[2], &c->d_pos_block[3], &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
+                             &c->d_rays[0], &c->d_rays[1], &c->d_rays[2], &c->d_rays[3], &c->d_rays[4], &c->d_rays[5], &c->d_acc[0], &c->d_acc[1], &c->d_acc[2], &c->d_out, &c->d_out8, &c->d_pixels, &c->d_jitter, &c->d_fc[0], &c->d_fc[1], &c->d_fc[2], &c->d_fc[3],
                              &c->d_dbg_in, &c->d_dbg_out};
         for (auto* b : bufs) release(*b);
         for (auto& f : c->slots) { f.traced = nullptr; if (f.h_report) { (void)hipHostFree(f.h_report); f.h_report = nullptr; f.d_report = nullptr; } for (auto e : f.events) (void)hipEventDestroy(e); f.events.clear(); }
@@ -347,7 +351,7 @@ void ft_destroy(ft_context* c) {
         for (hipEvent_t& e : c->acc_free) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (c->side) (void)hipStreamDestroy(c->side);
         if (c->tail) (void)hipStreamDestroy(c->tail);
-        if (c->stream2) (void)hipStreamDestroy(c->stream2);
+        for (hipStream_t m : c->more_mains) if (m) (void)hipStreamDestroy(m);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -369,7 +373,13 @@ int32_t ft_set_option(ft_context* c, const char* key, int64_t value) {
     if (!std::strcmp(key, "timing")) { if (value < 0 || value > 2) return FT_ERR_INVALID; c->timing = (int)value; for (ft_context* p : c->peers) p->timing = (int)value; return FT_OK; }
     if (!std::strcmp(key, "window_cap")) { if (value < 64 || value > (1ll << 30)) return FT_ERR_INVALID; c->window_cap = value; for (ft_context* p : c->peers) p->window_cap = value; return FT_OK; }
     if (!std::strcmp(key, "primary_reserve")) { if (value < 0 || value > 4096) return FT_ERR_INVALID; c->primary_reserve = value; for (ft_context* p : c->peers) p->primary_reserve = value; return FT_OK; }
-    if (!std::strcmp(key, "two_mains")) { c->two_mains = value != 0; for (ft_context* p : c->peers) p->two_mains = value != 0; return FT_OK; }
+    if (!std::strcmp(key, "two_mains") || !std::strcmp(key, "mains")) {
+        const int m = key[0] == 't' ? (value != 0 ? 2 : 1) : (int)value;
+        if (m < 1 || m > ft_context::kMains) return FT_ERR_INVALID;
+        auto set = [&](ft_context* p) { p->mains = p->more_mains[0] && p->more_mains[1] ? m : 1; };
+        set(c); for (ft_context* p : c->peers) set(p);
+        return FT_OK;
+    }
     if (!std::strcmp(key, "window_hint")) { c->window_hint = value != 0; for (ft_context* p : c->peers) p->window_hint = value != 0; return FT_OK; }
     if (!std::strcmp(key, "resolve_aside")) { c->resolve_aside = value != 0; for (ft_context* p : c->peers) p->resolve_aside = value != 0; return FT_OK; }
     if (!std::strcmp(key, "resolve_blocks")) { if (value < 0 || value > 8) return FT_ERR_INVALID; c->resolve_blocks_cap = (int)value; for (ft_context* p : c->peers) p->resolve_blocks_cap = (int)value; return FT_OK; }
@@ -990,8 +1000,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     const ft_context::FrameSlot& prevF = c->slots[(turn + ft_context::kSlots - 1) % ft_context::kSlots];
     const bool simple = defer && c->resolve_aside && !corner && c->timing < 2 && jobs.size() == 1;
     if (!simple && any_pending(c, true)) { int32_t prc = retire_pending(c, nullptr); if (prc != FT_OK) return prc; }   // anything else keeps the one-stream order
-    const bool alt = simple && c->two_mains && c->stream2 && !uploads_queued && prevF.pending && prevF.simple && !prevF.alt;   // the other stream than its predecessor's
-    const hipStream_t ms = alt ? c->stream2 : c->stream;
+    const int main_ix = (simple && c->mains > 1 && !uploads_queued && prevF.pending && prevF.simple) ? (prevF.main_ix + 1) % c->mains : 0;   // the next stream after its predecessor's
+    const bool alt = main_ix != 0;
+    const hipStream_t ms = alt ? c->more_mains[main_ix - 1] : c->stream;
     // chunk counters, statistic stripes, list length, tickets: cleared by the slot's previous frame's last kernel, or by a fill when there was none
     if (!c->fc_clean[turn]) { FT_HIP(c, hipMemsetAsync(fc, 0, sizeof(ftk::FrameCounters), ms)); uploads_queued = true; }
     c->fc_clean[turn] = false;                                     // until this frame's own hand-over is queued
@@ -1017,7 +1028,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     ftk::Launch Lg{ms, c->n_cu * 8, 0, 0};
     const int resolve_per_cu = c->resolve_blocks_cap > 0 ? std::min(c->resolve_blocks_cap, c->blocks_resolve) : c->blocks_resolve;
     ftk::Launch Lr{ms, c->n_cu * resolve_per_cu, 0, 0};
-    ftk::RayBuf rb[2] = {ray_view(c->d_rays[alt ? 2 : 0], c->ray_capacity), ray_view(c->d_rays[alt ? 3 : 1], c->ray_capacity)};
+    ftk::RayBuf rb[2] = {ray_view(c->d_rays[2 * main_ix], c->ray_capacity), ray_view(c->d_rays[2 * main_ix + 1], c->ray_capacity)};
 
     F.events_used = 0; F.spans.clear();
     auto& spans = F.spans;
@@ -1133,7 +1144,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
             if (boundary_fresh && boundary) F.traced = boundary;
             else { F.traced = next_event(F); if (!F.traced) { c->err = "hipEventCreate failed"; return FT_ERR_HIP; } FT_HIP(c, hipEventRecord(F.traced, ms)); }
         }
-        if (!aside) for (int k = 0; k < 2; ++k) if (c->acc_busy[k]) {   // a queued frame's k_resolve may still be writing the frame on `tail`: frames reach d_out in order
+        if (!aside) for (int k = 0; k < ft_context::kAcc; ++k) if (c->acc_busy[k]) {   // a queued frame's k_resolve may still be writing the frame on `tail`: frames reach d_out in order
             FT_HIP(c, hipStreamWaitEvent(ms, c->acc_free[k], 0)); c->acc_busy[k] = false; boundary_fresh = false;
         }
         if (corner) timed(kStageResolve, [&] { ftk::launch_resolve_corner(Lg, acc, n_samples, job.w, job.h, c->d_out_index.as<uint32_t>() + job.out_base, out_rgb, out_rgba); });
@@ -1153,7 +1164,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
                 if (!c->acc_free[at]) FT_HIP(c, hipEventCreateWithFlags(&c->acc_free[at], hipEventDisableTiming));
                 FT_HIP(c, hipEventRecord(c->acc_free[at], c->tail));
                 c->acc_busy[at] = true;
-                c->acc_turn ^= 1;
+                c->acc_turn = (c->acc_turn + 1) % ft_context::kAcc;
                 boundary_fresh = false;
             } else timed(kStageResolve, [&] { ftk::launch_resolve(Lr, ra); });
             if (last_job) c->fc_clean[turn] = true;
@@ -1174,7 +1185,7 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     else { ev1 = next_event(F); if (ev1) (void)hipEventRecord(ev1, ms); }
     FT_HIP(c, hipGetLastError());
     F.signature = signature; F.levels_launched = levels_launched; F.last_bounce = last_bounce;
-    F.simple = simple; F.alt = alt;
+    F.simple = simple; F.alt = alt; F.main_ix = main_ix;
     F.done = ev1;                                                  // nothing follows the last kernel: its end is the frame's
     F.ev0 = ev0; F.ev1 = ev1; F.pending = true; F.wall0 = wall0; F.timing = timing;
     F.rays_primary = 0; for (auto& j : jobs) F.rays_primary += (uint64_t)j.n_ids * (uint64_t)spp;

@@ -151,7 +151,8 @@ const char* ft_last_error(const ft_context* ctx);
  * surface-area split (the best tree, a slow build: 160 ms for 70 K triangles); 1: the device, a linear BVH (1 ms, traces ~9 % slower); 3: the device, a binned surface-area tree
  * over the Morton order (7 ms, traces like the host's); 2 = default: the host below 4096 triangles, the device's surface-area tree from there on),
  * "classify_ahead" / "resolve_aside" / "zero_fill_skip" (1 = default: what a stream of queued frames does that a single frame cannot - the next frame's k_classify on a second
- * stream, k_resolve on a third with the sample colours double-buffered, Colour.Zero not written again into blocks the last frame of the same signature left zero; 0 switches each off; k_resolve goes aside only in frames of one chunk), "two_mains" (1 = default: queued frames of one chunk without reflection levels alternate between two main streams, so a frame's k_primary is dispatched while its predecessor's drains; 0: one main stream), "primary_reserve" (0 = default: workgroup slots such a frame's k_primary leaves free for the small kernels queued beside it), "window_hint" (0 = default; 1: the chunks of a
+ * stream, k_resolve on a third with the sample colours double-buffered, Colour.Zero not written again into blocks the last frame of the same signature left zero; 0 switches each off; k_resolve goes aside only in frames of one chunk), "mains" (2 = default, 1 .. 3: queued frames of one chunk take turns on that many main streams, so a frame's kernels are dispatched while its predecessor's drain
+ * and two frames' reflection levels fill each other's idle stretches; "two_mains" = 0 / 1 is mains = 1 / 2), "primary_reserve" (0 = default: workgroup slots such a frame's k_primary leaves free for the small kernels queued beside it), "window_hint" (0 = default; 1: the chunks of a
  * classified frame are cut as wide as the last frame of the same scene, size and sample count left them room for, up to "window_cap" listed samples - fewer empty launches on sparse frames, measured no net gain), "wave_samples" (0 = default, 16: a bounce-0 wavefront takes up to that many jitter offsets of 64 / that many pixels of an
  * 8x8 block when the sample count has the power of two in it - a narrower bundle; 1, 2, 4, 8, 16; no pixel depends on it).  Scene-affecting options need a new ft_scene_commit. */
 int32_t ft_set_option(ft_context* ctx, const char* key, int64_t value);
@@ -224,15 +225,15 @@ void  ft_host_free(void* p);
 
 /* A queued frame that also leaves the device: the copy into host_out (res_v x res_h x 3 doubles, or x 4 bytes with rgba8 != 0) is queued
  * behind the frame's last kernel and is complete when ft_render_wait returns (or when a later call retires the frame).  host_out should
- * come from ft_host_alloc (one DMA beside the next frame's tracing); one buffer per frame in flight (three at most: a buffer is the host's again once
- * a later call has retired its frame - queuing frame k + 3 retires frame k - or ft_render_wait has returned). */
+ * come from ft_host_alloc (one DMA beside the next frame's tracing); one buffer per frame in flight (four at most: a buffer is the host's again once
+ * a later call has retired its frame - queuing frame k + 4 retires frame k - or ft_render_wait has returned). */
 int32_t ft_render_enqueue_into(ft_context* ctx, const ft_camera* cam, int32_t res_h, int32_t res_v, int32_t spp, const double* jitter_xy,
                                int32_t max_depth, uint64_t seed, const ft_rect* tiles, int32_t n_tiles, int32_t rgba8, void* host_out);
 
 /* Pipelined rendering, for hosts that render frame after frame (an animation, a progressive preview):
  * ft_render_enqueue queues a frame exactly as ft_render(out_rgb = NULL) would and returns without waiting, so the host prepares
- * the next frame while this one runs; at most three frames are in flight (queuing a fourth first waits for the oldest: one is traced, the next is
- * dispatched behind it on a second stream, the third is being classified).  On a context
+ * the next frame while this one runs; at most four frames are in flight (queuing a fifth first waits for the oldest: one or two are traced, the next
+ * waits dispatched on another stream, the last is being classified).  On a context
  * over several devices every device queues its bands on its own stream; ft_render_wait waits for all of them and sums their statistics.
  * ft_render_wait blocks until everything queued has finished, reports the statistics of the LAST frame, and leaves in
  * ft_get_kernel_times the stage times and launch counts summed over all frames since the previous wait.  The frame buffer holds

@@ -6,7 +6,7 @@ sys.path.insert(0, R)
 import functracer_amd as ft
 CASES = [("bunny", 1920, 1080, 16), ("bunny", 1920, 1080, 4), ("bunny", 3840, 2160, 64), ("bunny", 3840, 2160, 16), ("hollow-sphere", 1920, 1080, 1), ("hollow-sphere", 1920, 1080, 16),
          ("night-house-det", 1920, 1080, 16), ("bunny-bsp12", 1920, 1080, 16), ("moon", 1920, 1080, 16), ("repeat", 1920, 1080, 4), ("sample-det", 1920, 1080, 16)]
-SETTINGS = [(0, 0), (1, 0), (0, 1), (1, 1)]
+SETTINGS = [(1, 1)] if os.environ.get("FT_ONLY_DEFAULT") else [(0, 0), (1, 0), (0, 1), (1, 1)]
 ctx = ft.Context(0)
 for kv in filter(None, os.environ.get("FT_OPTS", "").split(",")):
     k, v = kv.split("="); ctx.set_option(k, int(v))
