@@ -913,7 +913,9 @@ static int32_t render_single(ft_context* c, const RenderRequest& q, void* out, f
     // (round 3: five times as wide, not twice - 80 Mi listed samples.  A frame of one window is a SIMPLE frame below: its k_resolve goes aside and its
     //  k_primary to the other main stream.  A rank's eighth of 3840x2160x64 - 66 M listed samples, 5 M of them active - was two windows, the
     //  second one empty: 0.458 -> 0.417 ms per frame as one; its half 1.69 -> 1.62, its quarter and the whole frame unchanged, tools/rank_share_ab.py)
-    int64_t chunk_budget = classify ? 5 * c->chunk_samples : c->chunk_samples;
+    // An unclassified frame without soft lights is worth one chunk of twice the width for the same reason (night-house-det 1080p x 16: two
+    // chunks 2.60 ms, one - a simple, pipelined frame - 2.46); with soft lights the narrow chunks still win (night-house: 3.62 against 3.75).
+    int64_t chunk_budget = classify ? 5 * c->chunk_samples : ((c->variant & 2) ? c->chunk_samples : 2 * c->chunk_samples);
     // The windows of a classified frame are cut from its LISTED pixels (the host does not know the active list's length when it queues
     // them), so a sparse frame is one window of work and a row of launches that find theirs empty (~20 us each: k_primary + k_resolve +
     // the counter fill; 3840x2160x64 of the bunny: 16 windows, 14 empty).  Option "window_hint" = 1: when the last frame of this
