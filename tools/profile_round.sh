@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats 
 cp $(ls gpurun_out/${tag}_stats/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats.csv
 python3 tools/trace_percentiles.py gpurun_out/${tag}_stats > gpurun_out/${tag}_kernel_percentiles.txt     # frames are pipelined: overlapped launches stretch one another (median vs mean)
 # the same command with the frame pipeline off: every kernel alone on the device (what bench.py reports as roofline.alone)
-FT_OPTS=classify_ahead=0,resolve_aside=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_serial -- $B > /dev/null 2>&1
+FT_OPTS=mains=1,classify_ahead=0,resolve_aside=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_serial -- $B > /dev/null 2>&1
 cp $(ls gpurun_out/${tag}_stats_serial/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_serial_kernel_stats.csv
 python3 tools/trace_percentiles.py gpurun_out/${tag}_stats_serial >> gpurun_out/${tag}_kernel_percentiles.txt
 FT_OPTS=zero_fill_skip=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -- $P > /dev/null 2>&1

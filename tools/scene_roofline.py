@@ -43,8 +43,10 @@ rays = {"k_primary": generated + rf.get("shadow_primary_rank0", 0),
 layout = {"k_primary": bench.get("layout_bytes_per_frame", {}).get("primary"), "k_bounce": bench.get("layout_bytes_per_frame", {}).get("shade")}
 ms = {"k_primary": per_kernel.get("primary", 0.0), "k_bounce": per_kernel.get("shade", 0.0)}
 n_launch = {"k_primary": launches.get("primary", 1), "k_bounce": launches.get("shade", 1)}
-out = {"workload": bench["config"]["workload"], "ms_per_step": bench["ms_per_step"], "kernel_ms_per_step": bench["kernel_ms_per_step"],
-       "mrays_s_traced": bench["value"], "rays_traced_per_frame": rf["traced_all_ranks"], "per_kernel_ms_per_step": per_kernel,
+queued = last_json(T + "_bench_queued.json") if os.path.exists(T + "_bench_queued.json") else bench
+out = {"workload": bench["config"]["workload"], "ms_per_step": queued["ms_per_step"], "ms_per_step_one_stream": bench["ms_per_step"],
+       "note": "kernel times: frames on ONE stream, every kernel alone on the device (FT_OPTS=mains=1,classify_ahead=0,resolve_aside=0); ms_per_step: the default, pipelined frame period", "kernel_ms_per_step": bench["kernel_ms_per_step"],
+       "mrays_s_traced": queued["value"], "rays_traced_per_frame": rf["traced_all_ranks"], "per_kernel_ms_per_step": per_kernel,
        "hbm_calibration": traffic.get("calibration", {}), "kernels": {}}
 for k in ("k_primary", "k_bounce"):
     if ms[k] <= 0 or rays[k] <= 0:
