@@ -164,6 +164,22 @@ def test_jitter_pattern_rule():                               # Jitter.fs:15-24:
     assert np.array_equal(ft.jitter_pattern(16), a[:16])
 
 
+def test_pipeline_options_are_validated():
+    """ft_set_option: the frame-pipeline tunables of round 3 (include/functracer_hip.h) accept their documented range and refuse anything else."""
+    ctx = ft.Context(host_only=True)
+    for key, good, bad in (("mains", (1, 2, 3), (0, 4, -1)), ("two_mains", (0, 1), ()), ("primary_reserve", (0, 64, 4096), (-1, 4097)),
+                           ("window_cap", (64, 80 << 20), (0, 63)), ("window_hint", (0, 1), ()), ("classify_ahead", (0, 1), ()),
+                           ("resolve_aside", (0, 1), ()), ("zero_fill_skip", (0, 1), ())):
+        for v in good:
+            ctx.set_option(key, v)
+        for v in bad:
+            with pytest.raises(ft.FtError):
+                ctx.set_option(key, v)
+    with pytest.raises(ft.FtError):
+        ctx.set_option("no_such_option", 1)
+    ctx.close()
+
+
 def test_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(H.ROOT, "include", "functracer_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
