@@ -340,6 +340,7 @@ void ft_destroy(ft_context* c) {
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
+        for (hipStream_t m : c->more_mains) if (m) (void)hipStreamSynchronize(m);
         if (c->side) (void)hipStreamSynchronize(c->side);
         if (c->tail) (void)hipStreamSynchronize(c->tail);
         DeviceBuf* bufs[] = {&c->d_leaves, &c->d_m2w, &c->d_materials, &c->d_lights, &c->d_program, &c->d_meshes, &c->d_nodes, &c->d_bleaves, &c->d_tris, &c->d_culls, &c->d_tri_orig, &c->d_textures, &c->d_tex_pixels, &c->d_cull_items, &c->d_cull_rows, &c->d_item_pc, &c->d_block_pos[0], &c->d_block_pos[1], &c->d_block_pos[2], &c->d_block_pos[3], &c->d_pos_block[0], &c->d_pos_block[1], &c->d_pos_block[2], &c->d_pos_block[3], &c->d_wave_counts, &c->d_wide, &c->d_mesh_wide, &c->d_coarse, &c->d_out_index,
@@ -633,6 +634,7 @@ static int32_t fetch_single(ft_context* c, void* out, int format) {
     if (format != c->last_format) { c->err = format == 1 ? "the last frame was rendered as FP64 RGB (ft_render): no RGBA8 frame to fetch" : "the last frame was rendered as RGBA8 (ft_render_rgba8): no FP64 frame to fetch"; return FT_ERR_STATE; }
     FT_HIP(c, hipSetDevice(c->device));
     FT_HIP(c, hipStreamSynchronize(c->stream));                     // frames queued with ft_render_enqueue may still be running (the streams are non-blocking)
+    for (hipStream_t m : c->more_mains) if (m) FT_HIP(c, hipStreamSynchronize(m));
     FT_HIP(c, hipStreamSynchronize(c->tail));                       // ... their k_resolve on its own stream
     return copy_frame_out(c, out, format, nullptr);
 }
