@@ -1686,6 +1686,7 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
         const uint32_t i = bi * B + lane_id();
         const uint32_t pid = pid_next;
         const bool active = i < n && lane_id() < B;
+        const unsigned long long clk_batch = FT_CLK_NOW();          // (diagnostic build: sections of a batch, slots 22 .. 27)
         // ---- closest hit; the geometry sees the offset ray (Shading.fs:135), the shaders the original one (Shading.fs:137)
         Ray ro{0, 0, 0, 0, 0, 0};
         {
@@ -1699,7 +1700,10 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
         Query<false> q;
         q.active = active; q.best_t = __builtin_inf(); q.id0 = ID_MISS; q.id1 = 0; q.max_dist = 0.0; q.blocked = false;
         bool overflow;
+        const unsigned long long clk_a = FT_CLK_NOW();
+        FT_CLK_ADD(22, clk_batch);
         trace<false, MESH>(S, ro, q, lds, overflow, coherent);
+        FT_CLK_ADD(23, clk_a);
         n_ovf_wave += (unsigned long long)__popcll(__ballot(overflow && active));
         const bool hit = active && q.id0 != ID_MISS;
         const unsigned long long hit_mask = __ballot(hit);
@@ -1715,7 +1719,9 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
                 if (SOFT) sample = (unsigned long long)pid * (unsigned long long)fresh(K)->gen.spp + at_of(bi).s;
             }
             unsigned long long vis_lo, vis_hi;
+            const unsigned long long clk_b = FT_CLK_NOW();
             light_visibility<SOFT, MESH>(S, sf, lit, sample, [&]() { return fresh(K)->gen.seed; }, 0, coherent, lds, vis_lo, vis_hi, n_shadow_wave, n_ovf_wave);
+            FT_CLK_ADD(24, clk_b);
             MaterialV mat = material_at(S, sf.material);
             if (FANCY) { if (hit && mat.texture >= 0) textured_colour(S, mat, sf.u, sf.v, mat.colour); }
             // the view ray is generated again here rather than kept in registers across the shadow traces (same arithmetic, same value)
@@ -1746,6 +1752,7 @@ __global__ __launch_bounds__(kBlock, BLOCKS) void k_primary(PrimaryArgs) {
             double* acc = Ka->acc; const uint32_t acc_stride = Ka->acc_stride;
             acc[i] = 1.0 * cr; acc[(size_t)acc_stride + i] = 1.0 * cg; acc[2 * (size_t)acc_stride + i] = 1.0 * cb;
         }
+        FT_CLK_ADD(25, clk_batch); FT_CLK_INC(26);
     }
     RenderCounters* mine = my_stats(fresh(K)->fc);
     wave_add(&mine->rays_shadow, n_shadow_wave);
