@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <math.h>
 #include <stdint.h>
@@ -410,7 +411,24 @@ __global__ __launch_bounds__(256) void k_sah_keys(const SahState* s, uint32_t n,
         if (axis == 3u) side = p - range_first[o] >= n_left[o] ? 1u : 0u;
         else { const double* tb = tri_boxes + 6ull * vals[p]; const double* nb = node_boxes + 6ull * (uint32_t)o; side = (uint32_t)bin_of(0.5 * (tb[axis] + tb[3 + axis]), nb[axis], nb[3 + axis]) >= b ? 1u : 0u; }
     }
-    keys[p] = seg_first[p] * 2u + side;
+    keys[p] = side;                                                 // the stable partition of every segment is a scan of these flags away (k_sah_scatter)
+}
+// The stable partition of every open node's range by side: rights[p] = flags set before position p (exclusive scan over all positions), so
+// within the segment that begins at f = seg_first[p] there are rights[p] - rights[f] of them before p and (p - f) minus that many lefts;
+// the lefts of an open node fill its first n_left positions in order, the rights the rest.  Positions outside open nodes carry flag 0
+// and keep their place.  (Round 3: this replaced a radix sort of (segment, side) keys over all n positions per round.)
+__global__ __launch_bounds__(256) void k_sah_scatter(const SahState* s, uint32_t n, const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout, const int32_t* __restrict__ node_of,
+                                                      const uint32_t* __restrict__ seg_first, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ rights,
+                                                      const uint32_t* __restrict__ n_left, const uint32_t* __restrict__ plane) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const int32_t o = node_of[p];
+    uint32_t dst = p;
+    if (o >= 0 && (uint32_t)o >= s->level_begin) {
+        const uint32_t f = seg_first[p], before_r = rights[p] - rights[f], before_l = (p - f) - before_r;
+        dst = flags[p] ? f + n_left[o] + before_r : f + before_l;
+    }
+    vout[dst] = vin[p];
 }
 // After the partition: every position of an open node moves into the child that now covers it.
 __global__ __launch_bounds__(256) void k_sah_descend(const SahState* s, uint32_t n, int32_t* node_of, uint32_t* seg_first, const uint32_t* __restrict__ range_first,
@@ -479,7 +497,7 @@ hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height,
         hipLaunchKernelGGL(k_bvh_prepare, grid, block, 0, stream, t.tris, t.first_global, n, tb, st);
         hipLaunchKernelGGL(k_bvh_morton, grid, block, 0, stream, tb, n, st, k0, v0);
         BVH_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, k0, k1, v0, v1, n, 0, 30, stream));
-        if (sah) { BVH_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes2, k0, k1, v0, v1, n, 0, key_bits, stream)); if (sort_bytes2 > sort_bytes) sort_bytes = sort_bytes2; }
+        if (sah) { BVH_HIP(rocprim::exclusive_scan(nullptr, sort_bytes2, k0, k1, 0u, n, rocprim::plus<uint32_t>(), stream)); if (sort_bytes2 > sort_bytes) sort_bytes = sort_bytes2; }
         BVH_HIP(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 16));
         BVH_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, k0, k1, v0, v1, n, 0, 30, stream));
         const uint32_t* vals = v1;                                  // sorted position -> triangle of the mesh
@@ -507,7 +525,8 @@ hipError_t build_lbvh(hipStream_t stream, const LbvhTarget& t, uint32_t* height,
                 hipLaunchKernelGGL(k_sah_bin, grid, block, 0, stream, ss, n, vin, node_of, tb, nb, bins);
                 hipLaunchKernelGGL(k_sah_split, dim3((open + 3u) / 4u), block, 0, stream, ss, bins, rf, rl, left, right, sb, plane, n_left, nb, lf, lc);
                 hipLaunchKernelGGL(k_sah_keys, grid, block, 0, stream, ss, n, vin, node_of, seg_first, tb, nb, plane, n_left, rf, kin);
-                BVH_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, kin, kout, vin, vout, n, 0, key_bits, stream));
+                BVH_HIP(rocprim::exclusive_scan(sort_tmp, sort_bytes, kin, kout, 0u, n, rocprim::plus<uint32_t>(), stream));
+                hipLaunchKernelGGL(k_sah_scatter, grid, block, 0, stream, ss, n, vin, vout, node_of, seg_first, kin, kout, n_left, plane);
                 { uint32_t* x = vin; vin = vout; vout = x; }
                 hipLaunchKernelGGL(k_sah_descend, grid, block, 0, stream, ss, n, node_of, seg_first, rf, n_left, left, right);
                 hipLaunchKernelGGL(k_sah_next_level, dim3(1), dim3(1), 0, stream, ss);
