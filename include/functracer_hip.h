@@ -149,7 +149,7 @@ const char* ft_last_error(const ft_context* ctx);
  * previous frame had no more rays than this are not worth a launch and are followed as well; -1 = default: two rays per SIMD of the device; 0: every level that had a ray), "mesh_unclipped_bvh" (non-default fast mode: ignore bspMesh depth, BVH over the original triangles; pixels may
  * differ from the reference-shaped clipped BSP in the last bits), "bvh_builder" (who builds the exact BVH of top-level-Leaf meshes at commit - 0: the host, a swept
  * surface-area split (the best tree, a slow build: 160 ms for 70 K triangles); 1: the device, a linear BVH (1 ms, traces ~9 % slower); 3: the device, a binned surface-area tree
- * over the Morton order (6 ms, traces like the host's or better); 2 = default: the host below 4096 triangles, the device's surface-area tree from there on),
+ * over the Morton order (5.5 ms, traces like the host's or better); 2 = default: the host below 4096 triangles, the device's surface-area tree from there on),
  * "classify_ahead" / "resolve_aside" / "zero_fill_skip" (1 = default: what a stream of queued frames does that a single frame cannot - the next frame's k_classify on a second
  * stream, k_resolve on a third with the sample colours double-buffered, Colour.Zero not written again into blocks the last frame of the same signature left zero; 0 switches each off; k_resolve goes aside only in frames of one chunk), "mains" (2 = default, 1 .. 3: queued frames of one chunk take turns on that many main streams, so a frame's kernels are dispatched while its predecessor's drain
  * and two frames' reflection levels fill each other's idle stretches; "two_mains" = 0 / 1 is mains = 1 / 2), "primary_reserve" (0 = default: workgroup slots such a frame's k_primary leaves free for the small kernels queued beside it), "window_hint" (0 = default; 1: the chunks of a
