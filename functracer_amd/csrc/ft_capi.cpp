@@ -156,6 +156,7 @@ struct ft_context {
     uint64_t active_signature = 0;
     int64_t window_cap = 64ll << 20; // option "window_cap": listed samples a hinted window may span
     int64_t primary_reserve = 0;     // option "primary_reserve": workgroup slots a simple frame's k_primary leaves free
+    int ray_sets = 0;                // main streams whose pair of ray buffers holds ray_capacity records
     int mains = 2;                   // option "mains" (1 .. 3): main streams in use (measured: 2 is best - the headline 0.263 / 0.231 / 0.249 ms with 1 / 2 / 3, hollow-sphere x1 0.703 / 0.471 / 0.470); "two_mains" = 0 is mains = 1
     bool window_hint = false;        // option "window_hint": 1 widens a classified frame's windows by what the last frame of its signature left inactive (see render_single)
     uint64_t commit_serial = 0;
@@ -219,9 +220,10 @@ ftk::RayBuf ray_view(const DeviceBuf& b, int64_t cap) {
 int32_t ensure_frame_buffers(ft_context* c, int64_t cap, bool reflective) {
     int32_t rc;
     if (cap > c->acc_capacity) { for (int k = 0; k < ft_context::kAcc; ++k) if ((rc = ensure(c, c->d_acc[k], (size_t)cap * 24)) != FT_OK) return rc; c->acc_capacity = cap; }
-    if (!reflective || cap <= c->ray_capacity) return FT_OK;
-    for (int i = 0; i < 2 * ft_context::kMains; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)cap * (7 * 8 + 4))) != FT_OK) return rc;   // a ping-pong pair per main stream
-    c->ray_capacity = cap;
+    if (!reflective || (cap <= c->ray_capacity && c->ray_sets >= c->mains)) return FT_OK;
+    const int64_t want = std::max(cap, c->ray_capacity);
+    for (int i = 0; i < 2 * c->mains; ++i) if ((rc = ensure(c, c->d_rays[i], (size_t)want * (7 * 8 + 4))) != FT_OK) return rc;   // a ping-pong pair per main stream in use
+    c->ray_capacity = want; c->ray_sets = c->mains;
     return FT_OK;
 }
 
