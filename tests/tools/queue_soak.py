@@ -2,7 +2,7 @@
 """Soak of the frame pipeline (GPU box): random sequences of queued frames - cameras, sizes, sample counts, tile lists, FP64 / RGBA8, with and
 without a host buffer behind them, `mains` 1 .. 3 - against the same frames rendered one blocking call at a time.  Every delivered buffer and
 the frame left on the device must equal its blocking twin bit for bit, and the last frame's ray counts must agree.
-python tests/tools/queue_soak.py [sequences per scene] [seed] [big]   (big: frames of 960x544 .. 1920x1080 at 4 .. 16 samples: the kernels then run long enough to overlap)"""
+python tests/tools/queue_soak.py [sequences per scene] [seed] [big] [multi]   (multi: a context of two sub-contexts on the one device; big: frames of 960x544 .. 1920x1080 at 4 .. 16 samples: the kernels then run long enough to overlap)"""
 import os
 import sys
 
@@ -14,8 +14,9 @@ import functracer_amd as ft
 
 n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-BIG = len(sys.argv) > 3
-ctx = ft.Context(0)
+BIG = "big" in sys.argv[3:]
+MULTI = "multi" in sys.argv[3:]     # ft_create with the device listed twice: two sub-contexts take the bands of every frame, each with its own pipeline
+ctx = ft.Context(device=[0, 0]) if MULTI else ft.Context(0)
 bad = 0
 total = 0
 for name in ("bunny", "hollow-sphere", "sample-det", "night-house-det", "moon", "bunny-bsp12"):
