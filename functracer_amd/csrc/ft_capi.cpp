@@ -63,14 +63,16 @@ struct DeviceWorker {
 
 constexpr int64_t kDeviceBvhMinTris = 4096;   // "bvh_builder" = 2: smaller meshes get the host's swept SAH tree (a few ms at most), larger ones the device's binned one
 struct ft_context {
-    static constexpr int kMains_minus_1 = 2;
+    static constexpr int kMains = 3;   // main streams at most: consecutive simple frames trace on different ones (option "mains" says how many are in use)
+    static constexpr int kAcc = kMains;   // copies of the sample colours: one per frame between its k_primary and its k_resolve
+    static constexpr int kSlots = kMains + 1;   // frames in flight: one per main stream + the one being classified ahead
     std::vector<ft_context*> peers;      // multi-device contexts: one more single-device context per extra GPU (scene replicated)
     std::vector<DeviceWorker*> workers;  // ... and one host thread per peer
     bool host_only = false;
     int device = -1;
     int n_cu = 0;
     hipStream_t stream = nullptr;
-    hipStream_t more_mains[kMains_minus_1] = {};   // further main streams: consecutive simple queued frames trace on different ones, so that a frame's kernels are dispatched while its predecessors' drain
+    hipStream_t more_mains[kMains - 1] = {};   // further main streams: consecutive simple queued frames trace on different ones, so that a frame's kernels are dispatched while its predecessors' drain
     std::string err;
 
     fth::SceneGraph graph;
@@ -97,9 +99,6 @@ struct ft_context {
     DeviceBuf d_leaves, d_m2w, d_materials, d_lights, d_program, d_meshes, d_nodes, d_bleaves, d_tris, d_culls, d_tri_orig, d_textures, d_tex_pixels, d_cull_items, d_cull_rows, d_item_pc, d_wave_counts, d_wide, d_mesh_wide, d_coarse;
     // What k_classify writes and the frame's later kernels read exists once per frame slot, so that a queued frame's classification can
     // run (on `side`, behind an event) while the frame before it is still tracing: block_pos / pos_block and the frame's counters.
-    static constexpr int kMains = 3;   // main streams: consecutive simple frames trace on different ones
-    static constexpr int kAcc = kMains;   // copies of the sample colours: one per frame between its k_primary and its k_resolve
-    static constexpr int kSlots = kMains + 1;   // frames in flight: one per main stream + the one being classified ahead
     DeviceBuf d_block_pos[kSlots], d_pos_block[kSlots], d_fc[kSlots];
     hipStream_t side = nullptr;     // the second stream: k_classify of frame N + 1 beside k_primary's tail / k_resolve of frame N (ft_render_enqueue)
     bool classify_ahead = true;     // option "classify_ahead": 0 keeps every kernel on the one stream
